@@ -1,0 +1,133 @@
+/*
+ * kvq.h -- C ABI of libkvq.so: the MI355X (gfx950) implementation of the Kindergarten-VQ-VAE
+ * Shelgon/Bagon training hot path.
+ *
+ * The reference has no FFI (it is pure Python on ATen); the boundary this library sits
+ * behind is the reference's nn.Module / function surface.  Each entry point below names the reference
+ * lines it replaces.  The Python host (kindergarten-vq-vae_amd/kvq/_ffi.py) binds exactly these symbols
+ * with ctypes and hands over raw device pointers (tensor.data_ptr()) and the current HIP stream.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative KVQ_E_* code on failure; the message of the last
+ *     failure on the calling thread is kvq_last_error().  Nothing throws, nothing is allocated or freed
+ *     on behalf of the caller, no host synchronisation happens: all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream).  All entry points are hipGraph-capturable.
+ *   - all pointers are DEVICE pointers unless the name ends in _host.
+ *   - tensors are dense row-major; "io dtype" is the storage type of activations (z, z_q, g_zq, g_z, logits):
+ *     KVQ_F32 or KVQ_BF16.  The codebook E and its gradient are always f32, all arithmetic is f32
+ *     (exact f32 MFMA for the distance contraction) whatever the io dtype.
+ *   - G = number of independent codebooks ("factors").  G = 1 is the reference.
+ *     Layouts: z[G,N,D], E[G,K,D], idx[G,N], loss[G], perplexity[G], counts[G,K].
+ *
+ * Numerics contract of the VQ forward ("kvq order v1", restated on the CPU in oracle/vq_oracle.c):
+ *   dot(n,k)  = one f32 fmaf chain over j, visiting each group of 8 consecutive j in the order
+ *               0,4,1,5,2,6,3,7 (the k-walk of v_mfma_f32_32x32x2_f32 fed by 16-byte fragments)
+ *   sq(x)     = fl(p0 + p1), p_h = fmaf chain of x[j]^2 over increasing j with (j mod 8)/4 == h
+ *   d(n,k)    = fl( fl(sq(z_n) + sq(e_k)) - fl(2*dot(n,k)) )            [VectorQuantizer.py:59-61]
+ *   idx(n)    = first k attaining the minimum (NaN counts as smallest, as torch.argmin) [:65]
+ *   z_q(n)    = fl( z_n + fl(e_idx - z_n) )                              [:72,:80]
+ *   loss      = fl(m + fl(beta*m)),  m = (sum of fl(e_idx - z_n)^2 in f64) / (N*D)     [:76-77]
+ *   perplexity= exp(-sum_k p_k*log(p_k + 1e-10)),  p_k = count_k / N  (f32)            [:84-85]
+ */
+#ifndef KVQ_H
+#define KVQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVQ_VERSION 100 /* 0.1.0 */
+
+/* io dtypes */
+#define KVQ_F32 0
+#define KVQ_BF16 1
+
+/* error codes */
+#define KVQ_OK 0
+#define KVQ_E_INVALID (-1)   /* bad argument (null pointer, non-positive size, unsupported dtype) */
+#define KVQ_E_WORKSPACE (-2) /* workspace too small / missing */
+#define KVQ_E_LAUNCH (-3)    /* HIP reported a launch error */
+#define KVQ_E_NODEVICE (-4)  /* no HIP device usable */
+
+int kvq_version(void);
+const char* kvq_last_error(void);
+
+/* Number of compute units / name of the device the calling thread would launch on (diagnostics only). */
+int kvq_device_info(int* cu_count, char* name, size_t name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * VectorQuantizer.forward  (models/shelgon3/VectorQuantizer.py:31-93)
+ *
+ *   z        [G,N,D] io dtype   encoder output, N = B*S tokens          (:52-55)
+ *   E        [G,K,D] f32        codebook = embedding.weight             (:25)
+ *   z_q      [G,N,D] io dtype   straight-through output value           (:72,:80)
+ *   idx      [G,N]   int64      min_encoding_indices                    (:65,:90)
+ *   loss     [G]     f32        codebook + commitment loss              (:76-77)
+ *   perplexity [G]   f32                                                (:84-85)
+ *   counts   [G,K]   f32        code usage histogram = sum(min_encodings,0); may be NULL
+ *   ws                         scratch of kvq_vq_workspace_bytes(N,K,D,G) bytes, 256-byte aligned
+ *
+ * One fused kernel per call does distances, argmin, gather, straight-through, per-token loss terms and
+ * the histogram; a second, single-workgroup kernel turns the partials into loss / perplexity.
+ * min_encodings ([N,K] one-hot, :67-68) is not produced here: see kvq_vq_one_hot.
+ */
+size_t kvq_vq_workspace_bytes(int64_t N, int K, int D, int G);
+
+int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G, int io_dtype, float beta,
+                   void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* Autograd of the above (implicit in the reference; closed form in SURVEY.md §8 row A8b):
+ *   g_z  = g_zq - s*fl(e_idx - z),            s = g_loss * 2/(N*D)
+ *   g_E[k] = beta*s * sum_{n: idx_n = k} fl(e_k - z_n)      (deterministic: ordered slab reduction, no atomics)
+ *   g_zq   [G,N,D] io dtype  upstream gradient of z_q (may be NULL = zeros)
+ *   g_loss [G]     f32       upstream gradient of loss, ON DEVICE (may be NULL = ones)
+ *   g_z    [G,N,D] io dtype ; g_E [G,K,D] f32 (overwritten, not accumulated); either may be NULL to skip.
+ */
+int kvq_vq_backward(const void* z, const float* E, const int64_t* idx, const void* g_zq, const float* g_loss,
+                    int64_t N, int K, int D, int G, int io_dtype, float beta,
+                    void* g_z, float* g_E, void* ws, size_t ws_bytes, void* stream);
+
+/* min_encodings = one_hot(idx) as f32 [N,K]  (VectorQuantizer.py:67-68).  Materialised only on request. */
+int kvq_vq_one_hot(const int64_t* idx, int64_t N, int K, float* enc, void* stream);
+
+/* Test hook: the f32 distance matrix d[N,K] exactly as the fused kernel sees it (fast MFMA path when
+ * `use_mfma` != 0 and the shape allows, otherwise the generic path).  Not used by the product path. */
+int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int D, int io_dtype,
+                           int use_mfma, float* d, void* stream);
+
+/* Which path kvq_vq_forward takes for a shape: 1 = f32-MFMA LDS-tiled kernel, 0 = generic kernel. */
+int kvq_vq_uses_mfma(int64_t N, int K, int D);
+
+/* EMA codebook update (extension named by BASELINE.json north_star; NOT in the reference -> default off):
+ *   n_k <- g*n_k + (1-g)*count_k ;  m_k <- g*m_k + (1-g)*sum_{idx_n=k} z_n ;
+ *   E_k <- m_k / ((n_k + eps)/(sum n + K*eps) * sum n)
+ *   ema_n [G,K] f32, ema_m [G,K,D] f32 and E are updated in place. */
+int kvq_vq_ema_update(const void* z, const int64_t* idx, int64_t N, int K, int D, int G, int io_dtype,
+                      float decay, float eps, float* ema_n, float* ema_m, float* E,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reconstruction loss of step()  (models/shelgon3/Trainer.py:94-101)
+ *
+ *   kl_div(log_softmax(logits), one_hot(ids), "batchmean")  ==  mean_n( logsumexp(logits_n) - logits_n[ids_n] )
+ *   recon_ids = argmax(softmax(logits)) == argmax(logits) (first maximum)
+ *
+ *   logits [N,V] io dtype ; target [N] int64 ; row_loss [N] f32 ; row_lse [N] f32 ; pred [N] int64
+ *   loss [1] f32 = mean(row_loss) ; acc [1] f32 = mean(pred == target)  (common/metrics.py:18-30)
+ * The [N,V] one-hot of the reference (1 GB at N=8192) is never built.
+ */
+int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, int io_dtype,
+                   float* row_loss, float* row_lse, int64_t* pred, float* loss, float* acc, void* stream);
+
+/* g_logits[n,v] = g_loss/N * (softmax(logits_n)[v] - [v == target_n]); may alias logits (in place). */
+int kvq_ce_backward(const void* logits, const int64_t* target, const float* row_lse, const float* g_loss,
+                    int64_t N, int V, int io_dtype, void* g_logits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVQ_H */

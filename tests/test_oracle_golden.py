@@ -1,0 +1,119 @@
+"""The CPU oracle (oracle/) against the golden vectors produced by the reference's own VectorQuantizer.
+
+This is what pins the oracle: every other parity test compares the HIP path with the oracle.
+"""
+import numpy as np
+import pytest
+
+from _golden_util import case_names, check_indices, load_case
+from oracle import vq_oracle as O
+
+CASES = case_names()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    O.build()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_c_oracle_forward_matches_reference(name):
+    c = load_case(name)
+    out = O.vq_forward(c["z"], c["E"], float(c["beta"]))
+    ndiff = check_indices(c, out["idx"])
+    if c["regime"] in ("separated", "onto_codes", "ties"):
+        assert ndiff == 0, f"{name}: {ndiff} index mismatches on a well-separated case"
+    if ndiff == 0:
+        # z_q is a pure function of (z, E, idx): bitwise equal to the reference  (VectorQuantizer.py:72,:80)
+        import hashlib
+        assert hashlib.sha256(out["z_q"].tobytes()).hexdigest() == c["sha_zq"]
+        if c["full"]:
+            assert np.array_equal(out["z_q"], c["z_q"])
+        np.testing.assert_allclose(out["perplexity"], c["perplexity"], rtol=2e-5)
+    # loss differs from the reference only by summation order of the mean
+    np.testing.assert_allclose(out["loss"], c["loss"], rtol=2e-6, atol=1e-12)
+    assert out["counts"].sum() == c["B"] * c["S"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_c_oracle_backward_matches_reference(name):
+    c = load_case(name)
+    # use the reference's own indices so that near-tie flips do not leak into the gradient check
+    gz, gE = O.vq_backward(c["z"], c["E"], c["idx"], c["g"], float(c["c"]), float(c["beta"]))
+    D = c["D"]
+    if c["full"]:
+        np.testing.assert_allclose(gz, c["grad_z"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(gE, c["grad_E"], rtol=2e-5, atol=1e-7)
+    else:
+        np.testing.assert_allclose(gz.reshape(-1, D)[c["tok_rows"]], c["grad_z_rows"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(gE[c["code_rows"]], c["grad_E_rows"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(gz.astype(np.float64).sum(), c["grad_z_sum"], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose((gz.astype(np.float64) ** 2).sum(), c["grad_z_sq"], rtol=1e-5)
+    np.testing.assert_allclose((gE.astype(np.float64) ** 2).sum(), c["grad_E_sq"], rtol=1e-4, atol=1e-12)
+    # codes nobody chose get exactly zero gradient
+    unused = np.setdiff1d(np.arange(c["K"]), c["idx"])
+    assert not gE[unused].any()
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if not n.startswith("k8192")])
+def test_torch_expr_restatement_matches_reference(name):
+    """The expression-for-expression torch restatement is the reference's op sequence: identical results."""
+    import torch
+    torch.set_num_threads(1)
+    c = load_case(name)
+    w = torch.from_numpy(c["E"].copy()).requires_grad_(True)
+    z = torch.from_numpy(c["z"].copy()).requires_grad_(True)
+    loss, z_q, perp, enc, idx = O.torch_expr_forward(z, w, float(c["beta"]))
+    assert np.array_equal(idx.reshape(-1).numpy(), c["idx"])
+    assert np.float32(loss.item()) == c["loss"] and np.float32(perp.item()) == c["perplexity"]
+    (float(c["c"]) * loss + (z_q * torch.from_numpy(c["g"])).sum()).backward()
+    if c["full"]:
+        assert np.array_equal(z.grad.numpy(), c["grad_z"]) and np.array_equal(w.grad.numpy(), c["grad_E"])
+    assert enc.shape == (c["B"] * c["S"], c["K"]) and idx.shape == (c["B"], c["S"], 1)
+
+
+def test_tie_rule_first_index_wins():
+    """Hand-made tie (SURVEY.md §8c golden item 3): duplicated codebook rows -> the lowest index is chosen."""
+    c = load_case("tiny_ties")
+    K = c["K"]
+    out = O.vq_forward(c["z"], c["E"], 0.25)
+    assert (out["idx"] < K - K // 2).all()
+    # exact duplicates of the winner exist at idx + K//2: distances are bitwise equal there
+    d = O.distances(c["z"], c["E"])
+    n = np.arange(d.shape[0])
+    assert np.array_equal(d[n, out["idx"]], d[n, out["idx"] + K // 2])
+
+
+def test_known_answer_identities():
+    """loss == (1+beta)*mean((E[idx]-z)^2); perplexity == exp(-sum p log(p+1e-10)); z_q == z+(E[idx]-z) bitwise."""
+    rng = np.random.default_rng(11)
+    z = rng.standard_normal((3, 9, 24), dtype=np.float32)
+    E = rng.standard_normal((13, 24), dtype=np.float32)
+    out = O.vq_forward(z, E, 0.4)
+    e = E[out["idx"]].reshape(z.shape)
+    assert np.array_equal(out["z_q"], z + (e - z))
+    np.testing.assert_allclose(out["loss"], 1.4 * np.mean((e.astype(np.float64) - z) ** 2), rtol=1e-6)
+    p = np.bincount(out["idx"], minlength=13) / 27.0
+    np.testing.assert_allclose(out["perplexity"], np.exp(-(p * np.log(p + 1e-10)).sum()), rtol=1e-5)
+    # nan rule of torch.argmin: a NaN distance wins
+    z2 = z.copy(); z2[0, 0, 0] = np.nan
+    assert O.vq_forward(z2, E, 0.4)["idx"][0] == 0
+
+
+def test_oracle_dot_order_is_documented_walk():
+    """kvq order v1: groups of 8 visited 0,4,1,5,2,6,3,7 as one fmaf chain."""
+    import ctypes as C
+    import math
+    lib = O.load()
+    rng = np.random.default_rng(5)
+    for D in (8, 16, 40, 13):
+        a = rng.standard_normal(D).astype(np.float32); b = rng.standard_normal(D).astype(np.float32)
+        acc = np.float32(0)
+        for g in range((D + 7) // 8):
+            for s in range(8):
+                j = 8 * g + (s >> 1) + ((s & 1) << 2)
+                if j < D:
+                    acc = np.float32(math.fma(float(a[j]), float(b[j]), float(acc))) if hasattr(math, "fma") else \
+                        np.float32(np.float64(a[j]) * np.float64(b[j]) + np.float64(acc))
+        got = lib.kvq_oracle_dot(a.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)), D)
+        assert np.float32(got) == acc
