@@ -1,0 +1,103 @@
+// kvq_common.h -- shared host/device helpers of libkvq.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "kvq.h"
+
+namespace kvq {
+
+// ---- error reporting (thread-local message, C-ABI never throws) -------------------------------------------
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define KVQ_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) return ::kvq::fail(KVQ_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- io dtype helpers --------------------------------------------------------------------------------------
+constexpr int WAVE = 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// round-to-nearest-even, NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ unsigned short f32_to_bf16(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <int DT>
+struct IO;
+
+template <>
+struct IO<KVQ_F32> {
+    typedef float elem;
+    static constexpr int bytes = 4;
+    // 4 consecutive elements starting at element offset `off` (off % 4 == 0, 16-byte aligned rows)
+    __device__ static __forceinline__ f32x4 load4(const void* base, size_t off) {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+    }
+    __device__ static __forceinline__ void store4(void* base, size_t off, f32x4 v) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+    }
+    __device__ static __forceinline__ float load1(const void* base, size_t off) {
+        return reinterpret_cast<const float*>(base)[off];
+    }
+    __device__ static __forceinline__ void store1(void* base, size_t off, float v) {
+        reinterpret_cast<float*>(base)[off] = v;
+    }
+    // value the consumer of a stored element will read back
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+
+template <>
+struct IO<KVQ_BF16> {
+    typedef unsigned short elem;
+    static constexpr int bytes = 2;
+    __device__ static __forceinline__ f32x4 load4(const void* base, size_t off) {
+        u16x4 r = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(base) + off);
+        f32x4 v = {bf16_to_f32(r.x), bf16_to_f32(r.y), bf16_to_f32(r.z), bf16_to_f32(r.w)};
+        return v;
+    }
+    __device__ static __forceinline__ void store4(void* base, size_t off, f32x4 v) {
+        u16x4 r = {f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
+        *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(base) + off) = r;
+    }
+    __device__ static __forceinline__ float load1(const void* base, size_t off) {
+        return bf16_to_f32(reinterpret_cast<const unsigned short*>(base)[off]);
+    }
+    __device__ static __forceinline__ void store1(void* base, size_t off, float v) {
+        reinterpret_cast<unsigned short*>(base)[off] = f32_to_bf16(v);
+    }
+    __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+
+// ---- wave-level reductions (64 lanes) ------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+    return v;
+}
+
+// torch.argmin ordering: strictly smaller wins; NaN is smaller than any number; equal -> lower index.
+__device__ __forceinline__ bool dist_less(float d, float best) { return (d < best) || ((d != d) && (best == best)); }
+__device__ __forceinline__ bool dist_equal(float a, float b) { return (a == b) || ((a != a) && (b != b)); }
+__device__ __forceinline__ bool cand_better(float d, int i, float bd, int bi) {
+    return dist_less(d, bd) || (dist_equal(d, bd) && i < bi);
+}
+
+}  // namespace kvq

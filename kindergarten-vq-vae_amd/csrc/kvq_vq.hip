@@ -1,0 +1,702 @@
+// kvq_vq.hip -- the VectorQuantizer codebook step on gfx950 (MI355X).
+//
+// Replaces models/shelgon3/VectorQuantizer.py:55-93 of the reference (distance, argmin, one-hot gather,
+// losses, straight-through, perplexity) and its autograd.  Numerics contract: include/kvq.h ("kvq order v1").
+//
+// Forward, fast path (D % 64 == 0): ONE fused kernel per call.
+//   workgroup = 32 tokens x all K codes, 8 waves (2 per SIMD); codes are swept 256 per pass, the contraction
+//   64 floats per stage.  Each stage's E tile [256 codes][64] and z tile [32 tokens][64] sit in LDS as 256-byte
+//   rows, 16-byte chunks XOR-swizzled by (row & 15) so that the ds_read_b128 fragment reads are conflict free;
+//   two stages are double buffered (144 KiB of the CU's 160 KiB) while the next stage's global loads are in
+//   flight.  The contraction runs on the exact-f32 matrix core instruction v_mfma_f32_32x32x2_f32 with the CODES
+//   as rows: a lane then owns one token and 16 codes of the 32x32 tile, so the running argmin is lane-local;
+//   the two half-waves are merged with one shuffle and the 8 waves through 2 KiB of LDS.  Row norms ||e||^2 and
+//   ||z||^2 fall out of the operand fragments the lanes already hold (one extra fmaf per operand element).
+//   Epilogue in the same kernel: gather E[idx], z_q = z + (e - z), per-token sum of squares (f64), histogram.
+//   A single-workgroup kernel then reduces the per-token terms to loss and perplexity in a fixed order
+//   (bitwise reproducible; no float atomics anywhere).
+// Forward, generic path (any D): one wave per token, same chain orders, scalar fmaf.
+// Backward: g_z elementwise; g_E by ordered slab reduction (per code, per token chunk, then chunks in order).
+#include <limits.h>
+#include <math.h>
+
+#include "kvq_common.h"
+
+namespace kvq {
+
+// =============================================================================================================
+// geometry of the fused MFMA kernel
+// =============================================================================================================
+constexpr int TM = 32;                 // tokens per workgroup
+constexpr int NWAVES = 8;              // waves per workgroup (2 per SIMD)
+constexpr int NTHREADS = NWAVES * WAVE;
+constexpr int CP = NWAVES * 32;        // codes per pass (one 32x32 tile per wave)
+constexpr int KC = 64;                 // contraction depth per stage, floats (256-byte LDS rows)
+constexpr int E_TILE = CP * KC;        // floats
+constexpr int Z_TILE = TM * KC;        // floats
+constexpr int STAGE = E_TILE + Z_TILE; // floats per stage: 18432 = 72 KiB
+constexpr int RED_OFF = 2 * STAGE;     // cross-wave argmin scratch behind the two stages
+constexpr int LDS_FLOATS = RED_OFF + 2 * NWAVES * TM + TM;
+constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+constexpr int E_CHUNKS_PER_THREAD = (CP * (KC / 4)) / NTHREADS;  // 8 16-byte chunks of E per thread per stage
+static_assert(TM * (KC / 4) == NTHREADS, "one z chunk per thread per stage");
+
+struct FwdParams {
+    const void* z;      // [G,N,D] io dtype
+    const float* E;     // [G,K,D]
+    void* z_q;          // [G,N,D] io dtype
+    int64_t* idx;       // [G,N]
+    double* tok_sumsq;  // ws [G,N]
+    unsigned* counts;   // ws [G,K]
+    const float* e2;    // ws [G,K]  (generic path only)
+    float* dump;        // optional [N,K] distances (debug hook), G == 1
+    int64_t N;
+    int K, D;
+};
+
+// -------------------------------------------------------------------------------------------------------------
+// per-token epilogue, executed by one full wave: gather, straight-through, squared error, histogram
+//   VectorQuantizer.py:72 (z_q = E[idx]), :76-77 (squared error), :80 (z + (z_q - z))
+// -------------------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ void token_epilogue(const FwdParams& p, int g, int64_t tok, int code, int lane) {
+    const size_t zrow = ((size_t)g * p.N + (size_t)tok) * p.D;
+    const float* e = p.E + ((size_t)g * p.K + (size_t)code) * p.D;
+    double ss = 0.0;
+    if ((p.D & 3) == 0) {
+        for (int c = lane; c < (p.D >> 2); c += WAVE) {
+            f32x4 zv = IO<DT>::load4(p.z, zrow + 4 * c);
+            f32x4 ev = *reinterpret_cast<const f32x4*>(e + 4 * c);
+            f32x4 df = ev - zv;        // fl(e - z)
+            f32x4 q = zv + df;         // fl(z + fl(e - z))
+            IO<DT>::store4(p.z_q, zrow + 4 * c, q);
+            ss += (double)df.x * (double)df.x + (double)df.y * (double)df.y;
+            ss += (double)df.z * (double)df.z + (double)df.w * (double)df.w;
+        }
+    } else {
+        for (int j = lane; j < p.D; j += WAVE) {
+            float zv = IO<DT>::load1(p.z, zrow + j);
+            float df = e[j] - zv;
+            IO<DT>::store1(p.z_q, zrow + j, zv + df);
+            ss += (double)df * (double)df;
+        }
+    }
+    ss = wave_sum_f64(ss);
+    if (lane == 0) {
+        p.tok_sumsq[(size_t)g * p.N + tok] = ss;
+        p.idx[(size_t)g * p.N + tok] = (int64_t)code;
+        atomicAdd(p.counts + (size_t)g * p.K + code, 1u);   // integer histogram: order independent, exact
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// staging helpers of the fused kernel (register staged: global -> VGPR early, VGPR -> LDS late)
+// -------------------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ void stage_issue(const FwdParams& p, const float* __restrict__ E, size_t zbase,
+                                            int64_t tok0, int pass, int kc, int tid,
+                                            f32x4 (&er)[E_CHUNKS_PER_THREAD], f32x4& zr) {
+#pragma unroll
+    for (int q = 0; q < E_CHUNKS_PER_THREAD; ++q) {
+        const int L = q * NTHREADS + tid;
+        const int r = L >> 4, c = L & 15;
+        int code = pass * CP + r;
+        code = code < p.K ? code : p.K - 1;   // padding rows: any valid row, masked out at the argmin
+        er[q] = *reinterpret_cast<const f32x4*>(E + (size_t)code * p.D + kc * KC + c * 4);
+    }
+    const int r = tid >> 4, c = tid & 15;
+    const int64_t tok = tok0 + r;
+    f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    zr = tok < p.N ? IO<DT>::load4(p.z, zbase + (size_t)tok * p.D + kc * KC + c * 4) : zero;
+}
+
+__device__ __forceinline__ void stage_commit(float* sb, int tid, const f32x4 (&er)[E_CHUNKS_PER_THREAD],
+                                             const f32x4& zr) {
+#pragma unroll
+    for (int q = 0; q < E_CHUNKS_PER_THREAD; ++q) {
+        const int L = q * NTHREADS + tid;
+        const int r = L >> 4, c = L & 15;
+        *reinterpret_cast<f32x4*>(sb + r * KC + ((c ^ (r & 15)) << 2)) = er[q];
+    }
+    const int r = tid >> 4, c = tid & 15;
+    *reinterpret_cast<f32x4*>(sb + E_TILE + r * KC + ((c ^ (r & 15)) << 2)) = zr;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// the fused forward kernel (fast path)
+// -------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(NTHREADS) void vq_fwd_mfma_kernel(FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y;
+    const int64_t tok0 = (int64_t)blockIdx.x * TM;
+    const float* __restrict__ E = p.E + (size_t)g * p.K * p.D;
+    const size_t zbase = (size_t)g * p.N * p.D;
+
+    const int nkc = p.D / KC;
+    const int npass = (p.K + CP - 1) / CP;
+    const int nst = npass * nkc;
+
+    f32x4 er[E_CHUNKS_PER_THREAD];
+    f32x4 zr;
+    stage_issue<DT>(p, E, zbase, tok0, 0, 0, tid, er, zr);
+    stage_commit(smem, tid, er, zr);
+    __syncthreads();
+
+    float best = INFINITY;
+    int bidx = INT_MAX;
+    f32x16 acc;
+    float pe = 0.f, pz = 0.f;
+    int pass = 0, kc = 0;
+
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nst;
+        int npass_next = pass, nkc_next = kc + 1;
+        if (nkc_next == nkc) { nkc_next = 0; npass_next = pass + 1; }
+        if (more) stage_issue<DT>(p, E, zbase, tok0, npass_next, nkc_next, tid, er, zr);
+
+        if (kc == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            pe = 0.f;
+            pz = 0.f;
+        }
+        // ---- 32 MFMAs: D[code][token] += E[code][k] * z[token][k], k = this stage's 64 floats in walk order
+        const float* sb = smem + buf * STAGE;
+        const float* erow = sb + (w * 32 + i) * KC;
+        const float* zrow = sb + E_TILE + i * KC;
+#pragma unroll
+        for (int gq = 0; gq < KC / 8; ++gq) {
+            const int slot = ((2 * gq + h) ^ (i & 15)) << 2;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(erow + slot);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(zrow + slot);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            pe = __builtin_fmaf(a.x, a.x, pe); pe = __builtin_fmaf(a.y, a.y, pe);
+            pe = __builtin_fmaf(a.z, a.z, pe); pe = __builtin_fmaf(a.w, a.w, pe);
+            pz = __builtin_fmaf(b.x, b.x, pz); pz = __builtin_fmaf(b.y, b.y, pz);
+            pz = __builtin_fmaf(b.z, b.z, pz); pz = __builtin_fmaf(b.w, b.w, pz);
+        }
+
+        if (more) stage_commit(smem + (buf ^ 1) * STAGE, tid, er, zr);
+
+        if (kc == nkc - 1) {
+            // ---- end of a pass: distances of this wave's 32 codes x 32 tokens, lane-local running argmin
+            const float z2 = pz + __shfl_xor(pz, 32, WAVE);   // sq(z_token): lanes i and i+32 hold the halves
+            const float e2v = pe + __shfl_xor(pe, 32, WAVE);  // sq(e_code i) of this wave's tile, in lanes i, i+32
+            const int cbase = pass * CP + w * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;   // row of the 32x32 C/D tile held in register r
+                const float e2r = __shfl(e2v, cl, WAVE);
+                const float t = z2 + e2r;                        // sum(z^2) + sum(e^2)      (:59-60)
+                const float dd = t - 2.0f * acc[r];              // ... - 2 z.e              (:61)
+                const int code = cbase + cl;
+                if (code < p.K) {
+                    if (p.dump && tok0 + i < p.N) p.dump[(size_t)(tok0 + i) * p.K + code] = dd;
+                    if (cand_better(dd, code, best, bidx)) { best = dd; bidx = code; }
+                }
+            }
+        }
+        __syncthreads();
+        kc = nkc_next;
+        pass = npass_next;
+    }
+
+    // ---- merge the two half-waves (same token, interleaved code sets), then the 8 waves through LDS
+    {
+        const float ob = __shfl_xor(best, 32, WAVE);
+        const int oi = __shfl_xor(bidx, 32, WAVE);
+        if (cand_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
+    }
+    float* red_val = smem + RED_OFF;
+    int* red_idx = reinterpret_cast<int*>(smem + RED_OFF + NWAVES * TM);
+    int* fin_idx = reinterpret_cast<int*>(smem + RED_OFF + 2 * NWAVES * TM);
+    if (lane < 32) {
+        red_val[w * TM + i] = best;
+        red_idx[w * TM + i] = bidx;
+    }
+    __syncthreads();
+    if (tid < TM) {
+        float b = red_val[tid];
+        int bi = red_idx[tid];
+#pragma unroll
+        for (int ww = 1; ww < NWAVES; ++ww) {
+            const float v = red_val[ww * TM + tid];
+            const int vi = red_idx[ww * TM + tid];
+            if (cand_better(v, vi, b, bi)) { b = v; bi = vi; }
+        }
+        fin_idx[tid] = bi;
+    }
+    __syncthreads();
+
+    // ---- epilogue: each wave finishes 4 tokens
+#pragma unroll 1
+    for (int t = 0; t < TM / NWAVES; ++t) {
+        const int ti = w * (TM / NWAVES) + t;
+        const int64_t tok = tok0 + ti;
+        if (tok < p.N) token_epilogue<DT>(p, g, tok, fin_idx[ti], lane);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// generic path: any D.  sq(e_k) first (one thread per code), then one wave per token.
+// -------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int walk8(int s) { return (s >> 1) + ((s & 1) << 2); }
+
+__global__ void row_sq_kernel(const float* __restrict__ E, int64_t rows, int D, float* __restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= rows) return;
+    const float* x = E + (size_t)k * D;
+    float p0 = 0.f, p1 = 0.f;
+    for (int j = 0; j < D; ++j) {
+        const float v = x[j];
+        if ((j & 7) < 4) p0 = __builtin_fmaf(v, v, p0);
+        else p1 = __builtin_fmaf(v, v, p1);
+    }
+    out[k] = p0 + p1;
+}
+
+constexpr int GEN_WAVES = 4;
+
+template <int DT>
+__global__ __launch_bounds__(GEN_WAVES* WAVE) void vq_fwd_generic_kernel(FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.y;
+    const int64_t tok = (int64_t)blockIdx.x * GEN_WAVES + w;
+    if (tok >= p.N) return;   // whole wave leaves together; no block-level barrier below
+    const int D = p.D;
+    const int D8 = (D + 7) & ~7;
+    float* zs = smem + (size_t)w * D8;
+    const size_t zrow = ((size_t)g * p.N + (size_t)tok) * D;
+    for (int j = lane; j < D8; j += WAVE) zs[j] = j < D ? IO<DT>::load1(p.z, zrow + j) : 0.f;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    // sq(z): two half chains
+    float p0 = 0.f, p1 = 0.f;
+    for (int j = 0; j < D; ++j) {
+        const float v = zs[j];
+        if ((j & 7) < 4) p0 = __builtin_fmaf(v, v, p0);
+        else p1 = __builtin_fmaf(v, v, p1);
+    }
+    const float z2 = p0 + p1;
+    const float* E = p.E + (size_t)g * p.K * D;
+    const float* e2 = p.e2 + (size_t)g * p.K;
+    float best = INFINITY;
+    int bidx = INT_MAX;
+    for (int k = lane; k < p.K; k += WAVE) {
+        const float* e = E + (size_t)k * D;
+        float acc = 0.f;
+        for (int g8 = 0; g8 < D8; g8 += 8) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int j = g8 + walk8(s);
+                const float ev = j < D ? e[j] : 0.f;
+                acc = __builtin_fmaf(zs[j], ev, acc);
+            }
+        }
+        const float t = z2 + e2[k];
+        const float dd = t - 2.0f * acc;
+        if (p.dump) p.dump[(size_t)tok * p.K + k] = dd;
+        if (cand_better(dd, k, best, bidx)) { best = dd; bidx = k; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ob = __shfl_xor(best, m, WAVE);
+        const int oi = __shfl_xor(bidx, m, WAVE);
+        if (cand_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
+    }
+    token_epilogue<DT>(p, g, tok, bidx, lane);
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// finalize: loss and perplexity from the per-token / per-code partials, fixed reduction order
+//   VectorQuantizer.py:76-77 and :84-85
+// -------------------------------------------------------------------------------------------------------------
+constexpr int FIN_THREADS = 256;
+
+__global__ __launch_bounds__(FIN_THREADS) void vq_finalize_kernel(const double* __restrict__ tok_sumsq,
+                                                                   const unsigned* __restrict__ counts_u,
+                                                                   int64_t N, int K, int D, float beta,
+                                                                   float* loss, float* perplexity, float* counts_f) {
+    __shared__ double sd[FIN_THREADS];
+    __shared__ float sf[FIN_THREADS];
+    const int g = blockIdx.x, t = threadIdx.x;
+    const double* ts = tok_sumsq + (size_t)g * N;
+    const unsigned* cu = counts_u + (size_t)g * K;
+    double a = 0.0;
+    for (int64_t n = t; n < N; n += FIN_THREADS) a += ts[n];
+    float ent = 0.f;
+    for (int k = t; k < K; k += FIN_THREADS) {
+        const float cnt = (float)cu[k];
+        if (counts_f) counts_f[(size_t)g * K + k] = cnt;
+        const float pk = cnt / (float)N;                 // e_mean                       (:84)
+        ent += pk * logf(pk + 1e-10f);
+    }
+    sd[t] = a;
+    sf[t] = ent;
+    __syncthreads();
+    for (int s = FIN_THREADS / 2; s > 0; s >>= 1) {
+        if (t < s) { sd[t] += sd[t + s]; sf[t] += sf[t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float m = (float)(sd[0] / ((double)N * (double)D));
+        const float bm = beta * m;
+        loss[g] = m + bm;                                 // mean(.) + beta*mean(.)       (:76-77)
+        perplexity[g] = expf(-sf[0]);                     // (:85)
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// backward
+// -------------------------------------------------------------------------------------------------------------
+struct BwdParams {
+    const void* z;
+    const float* E;
+    const int64_t* idx;
+    const void* g_zq;
+    const float* g_loss;
+    void* g_z;
+    float* g_E;
+    float* slab;   // ws [G,T,K,D]
+    int64_t N;
+    int K, D, T;
+    int64_t chunk;  // tokens per chunk (multiple of 64)
+    float beta;
+};
+
+// g_z = g_zq - s * fl(e_idx - z),  s = g_loss * 2/(N*D)          one wave per token
+template <int DT>
+__global__ __launch_bounds__(256) void vq_bwd_gz_kernel(BwdParams p) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.y;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + w;
+    if (tok >= p.N) return;
+    const float gl = p.g_loss ? p.g_loss[g] : 1.0f;
+    const float s = (float)((double)gl * 2.0 / ((double)p.N * (double)p.D));
+    const size_t row = ((size_t)g * p.N + (size_t)tok) * p.D;
+    const int code = (int)p.idx[(size_t)g * p.N + tok];
+    const float* e = p.E + ((size_t)g * p.K + code) * p.D;
+    if ((p.D & 3) == 0) {
+        for (int c = lane; c < (p.D >> 2); c += WAVE) {
+            const f32x4 zv = IO<DT>::load4(p.z, row + 4 * c);
+            const f32x4 ev = *reinterpret_cast<const f32x4*>(e + 4 * c);
+            f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+            if (p.g_zq) gq = IO<DT>::load4(p.g_zq, row + 4 * c);
+            const f32x4 df = ev - zv;
+            f32x4 o;
+            o.x = __builtin_fmaf(-s, df.x, gq.x); o.y = __builtin_fmaf(-s, df.y, gq.y);
+            o.z = __builtin_fmaf(-s, df.z, gq.z); o.w = __builtin_fmaf(-s, df.w, gq.w);
+            IO<DT>::store4(p.g_z, row + 4 * c, o);
+        }
+    } else {
+        for (int j = lane; j < p.D; j += WAVE) {
+            const float df = e[j] - IO<DT>::load1(p.z, row + j);
+            const float gq = p.g_zq ? IO<DT>::load1(p.g_zq, row + j) : 0.f;
+            IO<DT>::store1(p.g_z, row + j, __builtin_fmaf(-s, df, gq));
+        }
+    }
+}
+
+// slab[t][k][:] = sum over tokens n of chunk t with idx_n == k, in increasing n, of f(n)
+//   MODE 0: f = fl(e_k - z_n)   (codebook gradient)        MODE 1: f = z_n   (EMA cluster sums)
+// grid (K, T, G); each wave owns 64 float columns at a time; every wave scans the chunk's indices itself
+// (coalesced 64 at a time + ballot), so the visiting order is the token order: deterministic, no atomics.
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void vq_seg_sum_kernel(BwdParams p) {
+    const int k = blockIdx.x, t = blockIdx.y, g = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int64_t n0 = (int64_t)t * p.chunk;
+    const int64_t n1 = n0 + p.chunk < p.N ? n0 + p.chunk : p.N;
+    const int64_t* idx = p.idx + (size_t)g * p.N;
+    const float* e = p.E ? p.E + ((size_t)g * p.K + k) * p.D : nullptr;
+    float* out = p.slab + (((size_t)g * p.T + t) * p.K + k) * p.D;
+    // wave-uniform trip count (every lane of a wave takes part in each ballot); columns past D are masked
+    for (int j0 = (threadIdx.x & ~63); j0 < p.D; j0 += blockDim.x) {
+        const int j = j0 + lane;
+        const bool col = j < p.D;
+        float acc = 0.f;
+        const float ej = (MODE == 0 && col) ? e[j] : 0.f;
+        for (int64_t nb = n0; nb < n1; nb += WAVE) {
+            const int64_t n = nb + lane;
+            const bool hit = n < n1 && idx[n] == (int64_t)k;
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float zv = col ? IO<DT>::load1(p.z, ((size_t)g * p.N + (size_t)(nb + b)) * p.D + j) : 0.f;
+                acc += (MODE == 0) ? (ej - zv) : zv;
+            }
+        }
+        if (col) out[j] = acc;
+    }
+}
+
+// g_E[k][:] = beta * s * sum_t slab[t][k][:]   (t in increasing order)
+__global__ void vq_bwd_combine_kernel(BwdParams p) {
+    const int g = blockIdx.y;
+    const size_t KD = (size_t)p.K * p.D;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KD) return;
+    const float gl = p.g_loss ? p.g_loss[g] : 1.0f;
+    const float s = (float)((double)gl * 2.0 / ((double)p.N * (double)p.D));
+    const float* sl = p.slab + (size_t)g * p.T * KD + e;
+    float a = 0.f;
+    for (int t = 0; t < p.T; ++t) a += sl[(size_t)t * KD];
+    p.g_E[(size_t)g * KD + e] = (p.beta * s) * a;
+}
+
+// EMA apply (extension; textbook VQ-VAE EMA, see include/kvq.h)
+__global__ void vq_ema_counts_kernel(const int64_t* idx, int64_t N, int K, unsigned* cnt) {
+    const int g = blockIdx.y;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) atomicAdd(cnt + (size_t)g * K + idx[(size_t)g * N + n], 1u);
+}
+
+__global__ __launch_bounds__(256) void vq_ema_n_kernel(const unsigned* cnt, int K, float decay, float* ema_n,
+                                                        double* tot_out) {
+    __shared__ double sd[256];
+    const int g = blockIdx.x, t = threadIdx.x;
+    double a = 0.0;
+    for (int k = t; k < K; k += 256) {
+        const size_t i = (size_t)g * K + k;
+        const float v = (float)((double)decay * (double)ema_n[i] + (1.0 - (double)decay) * (double)cnt[i]);
+        ema_n[i] = v;
+        a += (double)v;
+    }
+    sd[t] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) sd[t] += sd[t + s];
+        __syncthreads();
+    }
+    if (t == 0) tot_out[g] = sd[0];
+}
+
+__global__ void vq_ema_apply_kernel(const float* slab, int T, int K, int D, float decay, float eps,
+                                    const float* ema_n, const double* tot, float* ema_m, float* E) {
+    const int g = blockIdx.y;
+    const size_t KD = (size_t)K * D;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KD) return;
+    const int k = (int)(e / D);
+    const float* sl = slab + (size_t)g * T * KD + e;
+    double sum = 0.0;
+    for (int t = 0; t < T; ++t) sum += (double)sl[(size_t)t * KD];
+    const double tt = tot[g];
+    const double nk = ((double)ema_n[(size_t)g * K + k] + (double)eps) / (tt + (double)K * (double)eps) * tt;
+    const size_t i = (size_t)g * KD + e;
+    const float m = (float)((double)decay * (double)ema_m[i] + (1.0 - (double)decay) * sum);
+    ema_m[i] = m;
+    E[i] = (float)((double)m / nk);
+}
+
+__global__ void vq_one_hot_kernel(const int64_t* __restrict__ idx, int64_t N, int K, float* __restrict__ enc) {
+    const size_t total = (size_t)N * K;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = e / K;
+        enc[e] = (int64_t)(e - n * K) == idx[n] ? 1.0f : 0.0f;
+    }
+}
+
+// =============================================================================================================
+// host side
+// =============================================================================================================
+static int pick_T(int64_t N, int K) {
+    // ~2048 (code, chunk) workgroups; chunk a multiple of 64 tokens
+    int64_t T = 1;
+    while (T * K < 2048 && (N + T * 2 - 1) / (T * 2) >= 64) T *= 2;
+    return (int)T;
+}
+static int64_t chunk_of(int64_t N, int T) { return ((N + T - 1) / T + 63) / 64 * 64; }
+
+struct WsLayout {
+    size_t counts, sumsq, e2, slab, total;
+};
+static WsLayout ws_layout(int64_t N, int K, int D, int G) {
+    WsLayout l;
+    size_t off = 0;
+    l.counts = off; off = align_up(off + (size_t)G * K * sizeof(unsigned), 256);
+    l.sumsq = off;  off = align_up(off + (size_t)G * N * sizeof(double), 256);
+    l.e2 = off;     off = align_up(off + (size_t)G * K * sizeof(float) + 16, 256);
+    l.slab = off;   off = align_up(off + (size_t)G * pick_T(N, K) * K * D * sizeof(float), 256);
+    l.total = off;
+    return l;
+}
+
+static bool mfma_ok(int64_t N, int K, int D) { return N > 0 && K > 0 && D > 0 && D % KC == 0; }
+
+template <int DT>
+static int launch_forward(FwdParams p, int G, bool use_mfma, hipStream_t st) {
+    if (use_mfma) {
+        static bool attr_done[2] = {false, false};
+        if (!attr_done[DT]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_fwd_mfma_kernel<DT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+            if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", LDS_BYTES, hipGetErrorString(e));
+            attr_done[DT] = true;
+        }
+        dim3 grid((unsigned)((p.N + TM - 1) / TM), (unsigned)G);
+        hipLaunchKernelGGL(vq_fwd_mfma_kernel<DT>, grid, dim3(NTHREADS), LDS_BYTES, st, p);
+        return check_launch("vq_fwd_mfma_kernel");
+    }
+    const int64_t rows = (int64_t)G * p.K;
+    hipLaunchKernelGGL(row_sq_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p.E, rows, p.D,
+                       const_cast<float*>(p.e2));
+    const size_t lds = (size_t)GEN_WAVES * ((p.D + 7) & ~7) * sizeof(float);
+    if (lds > 64 * 1024) return fail(KVQ_E_INVALID, "generic path: D=%d too large (needs D %% 64 == 0 above 4096)", p.D);
+    dim3 grid((unsigned)((p.N + GEN_WAVES - 1) / GEN_WAVES), (unsigned)G);
+    hipLaunchKernelGGL(vq_fwd_generic_kernel<DT>, grid, dim3(GEN_WAVES * WAVE), lds, st, p);
+    return check_launch("vq_fwd_generic_kernel");
+}
+
+}  // namespace kvq
+
+using namespace kvq;
+
+extern "C" {
+
+size_t kvq_vq_workspace_bytes(int64_t N, int K, int D, int G) {
+    if (N <= 0 || K <= 0 || D <= 0 || G <= 0) return 0;
+    return ws_layout(N, K, D, G).total;
+}
+
+int kvq_vq_uses_mfma(int64_t N, int K, int D) { return mfma_ok(N, K, D) ? 1 : 0; }
+
+int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G, int io_dtype, float beta,
+                   void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts, void* ws,
+                   size_t ws_bytes, void* stream) {
+    KVQ_REQUIRE(z && E && z_q && idx && loss && perplexity, "kvq_vq_forward: null pointer argument");
+    KVQ_REQUIRE(N > 0 && K > 0 && D > 0 && G > 0, "kvq_vq_forward: N=%lld K=%d D=%d G=%d must be positive", (long long)N, K, D, G);
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "kvq_vq_forward: unsupported io dtype %d", io_dtype);
+    KVQ_REQUIRE(N < (1ll << 31) * TM, "kvq_vq_forward: N too large");
+    const WsLayout l = ws_layout(N, K, D, G);
+    if (!ws || ws_bytes < l.total) return fail(KVQ_E_WORKSPACE, "kvq_vq_forward: workspace %zu < %zu bytes", ws_bytes, l.total);
+    KVQ_REQUIRE(((uintptr_t)ws & 255) == 0, "kvq_vq_forward: workspace must be 256-byte aligned");
+    KVQ_REQUIRE(((uintptr_t)z & 15) == 0 && ((uintptr_t)E & 15) == 0 && ((uintptr_t)z_q & 15) == 0,
+                "kvq_vq_forward: z, E, z_q must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)ws;
+    FwdParams p;
+    p.z = z; p.E = E; p.z_q = z_q; p.idx = idx;
+    p.tok_sumsq = (double*)(w + l.sumsq);
+    p.counts = (unsigned*)(w + l.counts);
+    p.e2 = (const float*)(w + l.e2);
+    p.dump = nullptr;
+    p.N = N; p.K = K; p.D = D;
+    hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)G * K * sizeof(unsigned), st);
+    if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    const bool fast = mfma_ok(N, K, D);
+    int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, G, fast, st) : launch_forward<KVQ_BF16>(p, G, fast, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)G), dim3(FIN_THREADS), 0, st, p.tok_sumsq, p.counts, N, K, D,
+                       beta, loss, perplexity, counts);
+    return check_launch("vq_finalize_kernel");
+}
+
+int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int D, int io_dtype, int use_mfma,
+                           float* d, void* stream) {
+    KVQ_REQUIRE(z && E && d && N > 0 && K > 0 && D > 0, "kvq_vq_debug_distances: bad argument");
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
+    if (use_mfma && !mfma_ok(N, K, D)) return fail(KVQ_E_INVALID, "shape N=%lld K=%d D=%d has no MFMA path", (long long)N, K, D);
+    // self-contained scratch (test hook only: allocation here is fine, this is never on the product path)
+    const WsLayout l = ws_layout(N, K, D, 1);
+    char* w = nullptr;
+    void *zq = nullptr, *ix = nullptr;
+    const size_t esz = io_dtype == KVQ_F32 ? 4 : 2;
+    if (hipMalloc((void**)&w, l.total) != hipSuccess || hipMalloc(&zq, (size_t)N * D * esz) != hipSuccess ||
+        hipMalloc(&ix, (size_t)N * 8) != hipSuccess)
+        return fail(KVQ_E_LAUNCH, "debug scratch allocation failed");
+    hipStream_t st = (hipStream_t)stream;
+    FwdParams p;
+    p.z = z; p.E = E; p.z_q = zq; p.idx = (int64_t*)ix;
+    p.tok_sumsq = (double*)(w + l.sumsq); p.counts = (unsigned*)(w + l.counts); p.e2 = (const float*)(w + l.e2);
+    p.dump = d; p.N = N; p.K = K; p.D = D;
+    (void)hipMemsetAsync(p.counts, 0, (size_t)K * sizeof(unsigned), st);
+    int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, 1, use_mfma != 0, st)
+                                 : launch_forward<KVQ_BF16>(p, 1, use_mfma != 0, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(w); (void)hipFree(zq); (void)hipFree(ix);
+    return rc;
+}
+
+int kvq_vq_backward(const void* z, const float* E, const int64_t* idx, const void* g_zq, const float* g_loss,
+                    int64_t N, int K, int D, int G, int io_dtype, float beta, void* g_z, float* g_E, void* ws,
+                    size_t ws_bytes, void* stream) {
+    KVQ_REQUIRE(z && E && idx, "kvq_vq_backward: null pointer argument");
+    KVQ_REQUIRE(N > 0 && K > 0 && D > 0 && G > 0, "kvq_vq_backward: sizes must be positive");
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "kvq_vq_backward: unsupported io dtype %d", io_dtype);
+    const WsLayout l = ws_layout(N, K, D, G);
+    if (g_E && (!ws || ws_bytes < l.total)) return fail(KVQ_E_WORKSPACE, "kvq_vq_backward: workspace %zu < %zu bytes", ws_bytes, l.total);
+    hipStream_t st = (hipStream_t)stream;
+    BwdParams p;
+    p.z = z; p.E = E; p.idx = idx; p.g_zq = g_zq; p.g_loss = g_loss; p.g_z = g_z; p.g_E = g_E;
+    p.slab = ws ? (float*)((char*)ws + l.slab) : nullptr;
+    p.N = N; p.K = K; p.D = D; p.T = pick_T(N, K); p.chunk = chunk_of(N, p.T); p.beta = beta;
+    if (g_z) {
+        dim3 grid((unsigned)((N + 3) / 4), (unsigned)G);
+        if (io_dtype == KVQ_F32) hipLaunchKernelGGL(vq_bwd_gz_kernel<KVQ_F32>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(vq_bwd_gz_kernel<KVQ_BF16>, grid, dim3(256), 0, st, p);
+        int rc = check_launch("vq_bwd_gz_kernel");
+        if (rc) return rc;
+    }
+    if (g_E) {
+        const int threads = D >= 256 ? 256 : (D + 63) / 64 * 64;
+        dim3 grid((unsigned)K, (unsigned)p.T, (unsigned)G);
+        if (io_dtype == KVQ_F32) hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_F32, 0>), grid, dim3(threads), 0, st, p);
+        else hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_BF16, 0>), grid, dim3(threads), 0, st, p);
+        int rc = check_launch("vq_seg_sum_kernel");
+        if (rc) return rc;
+        const size_t KD = (size_t)K * D;
+        hipLaunchKernelGGL(vq_bwd_combine_kernel, dim3((unsigned)((KD + 255) / 256), (unsigned)G), dim3(256), 0, st, p);
+        rc = check_launch("vq_bwd_combine_kernel");
+        if (rc) return rc;
+    }
+    return KVQ_OK;
+}
+
+int kvq_vq_ema_update(const void* z, const int64_t* idx, int64_t N, int K, int D, int G, int io_dtype, float decay,
+                      float eps, float* ema_n, float* ema_m, float* E, void* ws, size_t ws_bytes, void* stream) {
+    KVQ_REQUIRE(z && idx && ema_n && ema_m && E, "kvq_vq_ema_update: null pointer argument");
+    KVQ_REQUIRE(N > 0 && K > 0 && D > 0 && G > 0, "kvq_vq_ema_update: sizes must be positive");
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "kvq_vq_ema_update: unsupported io dtype %d", io_dtype);
+    const WsLayout l = ws_layout(N, K, D, G);
+    if (!ws || ws_bytes < l.total) return fail(KVQ_E_WORKSPACE, "kvq_vq_ema_update: workspace %zu < %zu bytes", ws_bytes, l.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)ws;
+    unsigned* cnt = (unsigned*)(w + l.counts);
+    double* tot = (double*)(w + l.sumsq);
+    BwdParams p;
+    p.z = z; p.E = nullptr; p.idx = idx; p.g_zq = nullptr; p.g_loss = nullptr; p.g_z = nullptr; p.g_E = nullptr;
+    p.slab = (float*)(w + l.slab);
+    p.N = N; p.K = K; p.D = D; p.T = pick_T(N, K); p.chunk = chunk_of(N, p.T); p.beta = 0.f;
+    (void)hipMemsetAsync(cnt, 0, (size_t)G * K * sizeof(unsigned), st);
+    hipLaunchKernelGGL(vq_ema_counts_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)G), dim3(256), 0, st, idx, N, K, cnt);
+    hipLaunchKernelGGL(vq_ema_n_kernel, dim3((unsigned)G), dim3(256), 0, st, cnt, K, decay, ema_n, tot);
+    const int threads = D >= 256 ? 256 : (D + 63) / 64 * 64;
+    dim3 grid((unsigned)K, (unsigned)p.T, (unsigned)G);
+    if (io_dtype == KVQ_F32) hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_F32, 1>), grid, dim3(threads), 0, st, p);
+    else hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_BF16, 1>), grid, dim3(threads), 0, st, p);
+    const size_t KD = (size_t)K * D;
+    hipLaunchKernelGGL(vq_ema_apply_kernel, dim3((unsigned)((KD + 255) / 256), (unsigned)G), dim3(256), 0, st, p.slab, p.T, K, D,
+                       decay, eps, ema_n, tot, ema_m, E);
+    return check_launch("vq_ema_update");
+}
+
+int kvq_vq_one_hot(const int64_t* idx, int64_t N, int K, float* enc, void* stream) {
+    KVQ_REQUIRE(idx && enc && N > 0 && K > 0, "kvq_vq_one_hot: bad argument");
+    const size_t total = (size_t)N * K;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(vq_one_hot_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, N, K, enc);
+    return check_launch("vq_one_hot_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+"""ctypes binding of libkvq.so -- the exact symbol list of include/kvq.h.
+
+The library is loaded lazily on first use and the load FAILS LOUDLY: there is no Python fallback for any
+of these entry points (a silent fallback would void every parity claim made for the HIP path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libkvq.so")
+
+KVQ_F32, KVQ_BF16 = 0, 1
+
+_vp, _i64, _int, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/kvq.h line by line
+SIGNATURES = {
+    "kvq_version": (_int, []),
+    "kvq_last_error": (C.c_char_p, []),
+    "kvq_device_info": (_int, [C.POINTER(_int), C.c_char_p, _sz]),
+    "kvq_vq_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
+    "kvq_vq_uses_mfma": (_int, [_i64, _int, _int]),
+    "kvq_vq_forward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kvq_vq_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "kvq_vq_one_hot": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "kvq_vq_debug_distances": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),
+    "kvq_vq_ema_update": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kvq_ce_forward": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kvq_ce_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
+}
+
+_lib = None
+
+
+class KvqError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises KvqError when libkvq.so has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KvqError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` or kindergarten-vq-vae_amd/build.sh. "
+                f"There is no CPU/eager fallback for the kvq ops.")
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 not found
+            raise KvqError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError as e:
+                raise KvqError(f"{LIB_PATH} does not export {name} (stale build?)") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().kvq_last_error()
+        raise KvqError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+def io_dtype_of(t) -> int:
+    import torch
+    if t.dtype == torch.float32:
+        return KVQ_F32
+    if t.dtype == torch.bfloat16:
+        return KVQ_BF16
+    raise KvqError(f"kvq ops take float32 or bfloat16 activations, got {t.dtype}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise KvqError(
+                "kvq ops run only on an MI355X (HIP) device: got a CPU tensor. There is deliberately no CPU "
+                "fallback; the CPU restatement lives in oracle/ and is test infrastructure only.")
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

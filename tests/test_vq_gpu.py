@@ -1,0 +1,240 @@
+"""GPU parity tests of the fused VQ step: libkvq.so (HIP, through the C ABI) against the CPU oracle and the
+golden vectors of the reference.  Bar: indices and z_q bit-exact; loss/perplexity/gradients to stated tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from _golden_util import case_names, check_indices, load_case
+from oracle import vq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = case_names()
+
+
+@pytest.fixture(scope="module")
+def kvq():
+    import kvq as _k
+    from kvq import _ffi
+    _ffi.lib()   # fails loudly if libkvq.so is missing
+    assert torch.cuda.is_available()
+    O.build()
+    return _k
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def _run(kvq, z, E, beta, g=None, c=1.0):
+    zt = _dev(z).reshape(-1, z.shape[-1]).requires_grad_(True)
+    Et = _dev(E).requires_grad_(True)
+    loss, z_q, perp, idx, counts = kvq.vector_quantize(zt, Et, beta)
+    out = dict(loss=loss.item(), z_q=z_q.detach().cpu().numpy(), perplexity=perp.item(), idx=idx.cpu().numpy(),
+               counts=counts.cpu().numpy())
+    if g is not None:
+        (float(c) * loss + (z_q * _dev(g).reshape(z_q.shape)).sum()).backward()
+        out["grad_z"] = zt.grad.cpu().numpy()
+        out["grad_E"] = Et.grad.cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_bit_exact_vs_oracle_and_reference(kvq, name):
+    c = load_case(name)
+    D = c["D"]
+    got = _run(kvq, c["z"], c["E"], float(c["beta"]))
+    ora = O.vq_forward(c["z"], c["E"], float(c["beta"]))
+    # HIP == oracle: indices and z_q bit for bit (same summation order by construction)
+    assert np.array_equal(got["idx"], ora["idx"]), f"{name}: {(got['idx'] != ora['idx']).sum()} indices differ from the oracle"
+    assert np.array_equal(got["z_q"], ora["z_q"].reshape(-1, D))
+    assert np.array_equal(got["counts"], ora["counts"])
+    np.testing.assert_allclose(got["loss"], ora["loss"], rtol=1e-6)         # f64-accumulated on both sides
+    np.testing.assert_allclose(got["perplexity"], ora["perplexity"], rtol=1e-5)
+    # HIP == reference golden: exact where the reference itself is stable, minimiser-within-ulps on near ties
+    ndiff = check_indices(c, got["idx"])
+    if c["regime"] != "default_init":
+        assert ndiff == 0
+    np.testing.assert_allclose(got["loss"], c["loss"], rtol=2e-6)
+    if ndiff == 0:
+        np.testing.assert_allclose(got["perplexity"], c["perplexity"], rtol=2e-5)
+        if c["full"]:
+            assert np.array_equal(got["z_q"], c["z_q"].reshape(-1, D))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_backward_vs_oracle_and_reference(kvq, name):
+    c = load_case(name)
+    D = c["D"]
+    got = _run(kvq, c["z"], c["E"], float(c["beta"]), c["g"], c["c"])
+    gz, gE = O.vq_backward(c["z"], c["E"], got["idx"], c["g"], float(c["c"]), float(c["beta"]))
+    np.testing.assert_allclose(got["grad_z"], gz.reshape(-1, D), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(got["grad_E"], gE, rtol=2e-5, atol=1e-7)
+    if np.array_equal(got["idx"], c["idx"]):
+        if c["full"]:
+            np.testing.assert_allclose(got["grad_z"], c["grad_z"].reshape(-1, D), rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(got["grad_E"], c["grad_E"], rtol=2e-5, atol=1e-7)
+        else:
+            np.testing.assert_allclose(got["grad_z"][c["tok_rows"]], c["grad_z_rows"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(got["grad_E"][c["code_rows"]], c["grad_E_rows"], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose((got["grad_E"].astype(np.float64) ** 2).sum(), c["grad_E_sq"], rtol=1e-4, atol=1e-12)
+    unused = np.setdiff1d(np.arange(c["K"]), got["idx"])
+    assert not got["grad_E"][unused].any()
+
+
+@pytest.mark.parametrize("shape", [(64, 512, 768), (100, 300, 128), (33, 37, 64), (256, 8192, 64)])
+@pytest.mark.parametrize("regime", ["sep", "near_tie"])
+def test_mfma_distances_bitwise_equal_oracle(kvq, shape, regime):
+    """The f32 MFMA contraction must be the documented fmaf chain: distance matrices equal bit for bit."""
+    N, K, D = shape
+    rng = np.random.default_rng(N + K + D)
+    z = rng.standard_normal((N, D), dtype=np.float32)
+    E = rng.standard_normal((K, D), dtype=np.float32) if regime == "sep" else \
+        rng.uniform(-1.0 / K, 1.0 / K, (K, D)).astype(np.float32)
+    assert kvq._ffi.lib().kvq_vq_uses_mfma(N, K, D) == 1
+    d_ref = O.distances(z, E)
+    d_mfma = kvq.vq_debug_distances(_dev(z), _dev(E), use_mfma=True).cpu().numpy()
+    d_gen = kvq.vq_debug_distances(_dev(z), _dev(E), use_mfma=False).cpu().numpy()
+    assert np.array_equal(d_gen.view(np.uint32), d_ref.view(np.uint32)), "generic kernel != oracle"
+    assert np.array_equal(d_mfma.view(np.uint32), d_ref.view(np.uint32)), "MFMA kernel != oracle"
+
+
+def test_ties_first_index_and_nan_rule(kvq):
+    c = load_case("tiny_ties")
+    got = _run(kvq, c["z"], c["E"], 0.25)
+    assert (got["idx"] < c["K"] - c["K"] // 2).all()
+    # big duplicated codebook on the MFMA path: duplicates sit in other waves / other passes
+    rng = np.random.default_rng(3)
+    E = rng.standard_normal((300, 64), dtype=np.float32)
+    E = np.concatenate([E, E, E])                    # K = 900: 4 passes of 256, copies 300 and 600 apart
+    z = rng.standard_normal((70, 64), dtype=np.float32)
+    got = _run(kvq, z, E, 0.25)
+    assert (got["idx"] < 300).all()
+    assert np.array_equal(got["idx"], O.vq_forward(z, E, 0.25)["idx"])
+    z[5, 3] = np.nan                                  # NaN distance row: torch.argmin returns the first index
+    got = _run(kvq, z, E, 0.25)
+    assert got["idx"][5] == 0
+
+
+def test_bf16_io_matches_oracle_on_upcast_inputs(kvq):
+    """bf16 activations are upcast exactly, all arithmetic stays f32: indices equal the oracle on the upcast z."""
+    rng = np.random.default_rng(8)
+    N, K, D = 256, 512, 768
+    z = torch.from_numpy(rng.standard_normal((N, D), dtype=np.float32)).bfloat16()
+    E = rng.standard_normal((K, D), dtype=np.float32)
+    zt = z.cuda().requires_grad_(True)
+    Et = _dev(E).requires_grad_(True)
+    loss, z_q, perp, idx, counts = kvq.vector_quantize(zt, Et, 0.25)
+    ora = O.vq_forward(z.float().numpy(), E, 0.25)
+    assert np.array_equal(idx.cpu().numpy(), ora["idx"])
+    assert z_q.dtype == torch.bfloat16
+    assert torch.equal(z_q.cpu(), torch.from_numpy(ora["z_q"]).bfloat16())
+    np.testing.assert_allclose(loss.item(), ora["loss"], rtol=1e-4)   # north_star: bf16 losses within 1e-4 relative
+    g = torch.from_numpy(rng.standard_normal((N, D), dtype=np.float32)).bfloat16()
+    (loss + (z_q.float() * g.cuda().float()).sum()).backward()
+    gz, gE = O.vq_backward(z.float().numpy(), E, ora["idx"], g.float().numpy(), 1.0, 0.25)
+    np.testing.assert_allclose(zt.grad.float().cpu().numpy(), gz, rtol=1e-2, atol=1e-6)
+    np.testing.assert_allclose(Et.grad.cpu().numpy(), gE, rtol=2e-5, atol=1e-7)
+
+
+def test_grouped_codebooks_equal_independent_calls(kvq):
+    """G codebooks in one launch == G separate calls."""
+    rng = np.random.default_rng(21)
+    G, N, K, D = 3, 96, 128, 64
+    z = rng.standard_normal((G, N, D), dtype=np.float32)
+    E = rng.standard_normal((G, K, D), dtype=np.float32)
+    loss, z_q, perp, idx, counts = kvq.vector_quantize(_dev(z), _dev(E), 0.3)
+    for g in range(G):
+        ora = O.vq_forward(z[g], E[g], 0.3)
+        assert np.array_equal(idx[g].cpu().numpy(), ora["idx"])
+        assert np.array_equal(z_q[g].cpu().numpy(), ora["z_q"])
+        np.testing.assert_allclose(loss[g].item(), ora["loss"], rtol=1e-6)
+        np.testing.assert_allclose(perp[g].item(), ora["perplexity"], rtol=1e-5)
+
+
+def test_full_size_properties_c2(kvq):
+    """BASELINE config 2 shape (N=8192, K=512, D=768): size-independent properties instead of a CPU recompute."""
+    torch.manual_seed(0)
+    N, K, D = 8192, 512, 768
+    z = torch.randn(N, D, device="cuda")
+    E = torch.randn(K, D, device="cuda")
+    loss, z_q, perp, idx, counts = kvq.vector_quantize(z, E, 0.25)
+    e = E[idx]
+    assert torch.equal(z_q, z + (e - z))                                     # straight-through value identity
+    np.testing.assert_allclose(loss.item(), 1.25 * ((e - z).double() ** 2).mean().item(), rtol=1e-6)
+    assert counts.sum().item() == N and torch.equal(counts, torch.bincount(idx, minlength=K).float())
+    # idempotence: quantising the codes themselves returns each code's own (first) index with zero loss
+    l2, zq2, _, idx2, _ = kvq.vector_quantize(E.clone(), E, 0.25)
+    assert torch.equal(idx2, torch.arange(K, device="cuda")) and l2.item() == 0.0 and torch.equal(zq2, E)
+    # optimality: no code is closer (fp64 check on a token sample)
+    sel = torch.randperm(N, device="cuda")[:256]
+    d = torch.cdist(z[sel].double(), E.double()) ** 2
+    chosen = d.gather(1, idx[sel, None]).squeeze(1)
+    assert (chosen - d.min(1).values <= 1e-3).all()
+    # permutation equivariance over tokens
+    perm = torch.randperm(N, device="cuda")
+    _, _, _, idx_p, _ = kvq.vector_quantize(z[perm].contiguous(), E, 0.25)
+    assert torch.equal(idx_p, idx[perm])
+    # determinism (no float atomics): two runs are bitwise equal, backward included
+    zr = z.clone().requires_grad_(True); Er = E.clone().requires_grad_(True)
+    la, zqa, *_ = kvq.vector_quantize(zr, Er, 0.25); (la + zqa.sum()).backward()
+    zr2 = z.clone().requires_grad_(True); Er2 = E.clone().requires_grad_(True)
+    lb, zqb, *_ = kvq.vector_quantize(zr2, Er2, 0.25); (lb + zqb.sum()).backward()
+    assert la.item() == lb.item() and torch.equal(Er.grad, Er2.grad) and torch.equal(zr.grad, zr2.grad)
+
+
+def test_large_codebook_c4(kvq):
+    """BASELINE config 4 (K=8192): 32 passes over the codebook; compare a token sample with the oracle."""
+    rng = np.random.default_rng(4)
+    N, K, D = 2048, 8192, 768
+    z = rng.standard_normal((N, D), dtype=np.float32)
+    E = rng.standard_normal((K, D), dtype=np.float32)
+    loss, z_q, perp, idx, counts = kvq.vector_quantize(_dev(z), _dev(E), 0.25)
+    O.set_threads(8)
+    ora = O.vq_forward(z[:128], E, 0.25)
+    O.set_threads(1)
+    assert np.array_equal(idx[:128].cpu().numpy(), ora["idx"])
+    assert counts.sum().item() == N
+
+
+def test_module_surface_matches_reference(kvq):
+    """nn.Module drop-in: ctor, parameter name, 5-tuple, shapes and dtypes (VectorQuantizer.py:19-29,:93)."""
+    from models.shelgon3.VectorQuantizer import VectorQuantizer
+    torch.manual_seed(0)
+    vq = VectorQuantizer(n_e=10, e_dim=768, beta=0.69).cuda()
+    assert list(vq.state_dict().keys()) == ["embedding.weight"] and len(list(vq.buffers())) == 0
+    assert vq.embedding.weight.abs().max().item() <= 0.1
+    z = torch.rand(16, 7, 768, device="cuda", requires_grad=True)          # the reference's demo shape (:100-110)
+    loss, z_q, perp, enc, idx = vq.forward(z, "cuda")
+    assert loss.dim() == 0 and perp.dim() == 0
+    assert z_q.shape == z.shape and enc.shape == (112, 10) and enc.dtype == torch.float32
+    assert idx.shape == (16, 7, 1) and idx.dtype == torch.int64
+    assert torch.equal(enc.argmax(1), idx.reshape(-1)) and torch.equal(enc.sum(1), torch.ones(112, device="cuda"))
+    (loss + z_q.sum()).backward()
+    assert z.grad is not None and vq.embedding.weight.grad is not None
+    init = torch.randn(10, 768)
+    vq2 = VectorQuantizer(10, 768, 0.25, vq_codebook_init_values=init)
+    assert torch.equal(vq2.embedding.weight.data, init)
+    with pytest.raises(RuntimeError):
+        vq.forward(torch.rand(4, 768, 7, device="cuda").transpose(1, 2), "cuda")   # non-contiguous, like .view
+    with pytest.raises(RuntimeError):
+        vq.forward(torch.rand(4, 7, 100, device="cuda"), "cuda")
+    from kvq._ffi import KvqError
+    with pytest.raises(KvqError):
+        vq.cpu().forward(torch.rand(2, 3, 768), "cpu")                               # no CPU fallback, by design
+
+
+def test_ema_update_matches_textbook_oracle(kvq):
+    rng = np.random.default_rng(2)
+    N, K, D = 500, 32, 64
+    z = rng.standard_normal((N, D), dtype=np.float32)
+    E = rng.standard_normal((K, D), dtype=np.float32)
+    idx = O.vq_forward(z, E, 0.25)["idx"]
+    ema_n = np.ones(K, np.float32); ema_m = E.copy()
+    n2, m2, E2 = O.vq_ema_update(z, idx, 0.99, 1e-5, ema_n, ema_m, E)
+    tn, tm, tE = _dev(ema_n), _dev(ema_m), _dev(E)
+    kvq.vq_ema_update(_dev(z), _dev(idx), tn, tm, tE, 0.99, 1e-5)
+    np.testing.assert_allclose(tn.cpu().numpy(), n2, rtol=1e-6)
+    np.testing.assert_allclose(tm.cpu().numpy(), m2, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tE.cpu().numpy(), E2, rtol=1e-5, atol=1e-6)
