@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- dSentences train sentences/sec of the Shelgon (BERT-base enc/dec + VQ K=512, D=768) step on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.  A "step" = tokenised batch already in HBM -> encoder -> fused VQ -> decoder ->
+fused LM-head loss -> backward -> (RCCL gradient all-reduce, overlapped) -> Adam.  Workload = BASELINE.json
+configs[1]: bf16, seq_len 32, per-GPU batch 256, `full` mode (all 247.8 M parameters trained), dropout active.
+Weak scaling: per-GPU batch is fixed, global batch = 256*N.
+
+Extra objects on the line:
+  roofline     the fused VQ kernel (vq_fwd_mfma_kernel), timed with HIP events around every launch of the timed
+               region on the stream it runs on; bound = f32 MFMA (exact-f32 distances), HBM figure beside it
+  cpu_baseline oracle/step_oracle.py (CPU f32 restatement, "port") timed on this host's cores, rank 0 at N=1 only
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BERT_BASE = dict()   # BertConfig() defaults = bert-base-uncased architecture
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA peak
+HBM_PEAK_GBPS = 8000.0         # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="sentences per GPU")
+    ap.add_argument("--seq-len", type=int, default=32)
+    ap.add_argument("--codes", type=int, default=512)
+    ap.add_argument("--mode", default="full")
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--model", default="bert-base-uncased")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--bucket-mib", type=int, default=64)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    from kvq import _ffi, ddp
+    from dsentences.synthetic import random_token_batch
+    from models.shelgon3.Shelgon import Shelgon
+    from models.shelgon3.VectorQuantizer import VectorQuantizer
+
+    rank, local, world = ddp.init_distributed()
+    if world != a.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    lib = _ffi.lib()
+
+    dtype = getattr(torch, a.dtype)
+    torch.manual_seed(0)
+    from models.bagon.Bagon import LOCAL_BERT_CONFIGS
+    hidden = LOCAL_BERT_CONFIGS[a.model].get("hidden_size", 768)
+    vq = VectorQuantizer(n_e=a.codes, e_dim=hidden, beta=0.25)
+    vq.materialize_min_encodings = False
+    model = Shelgon(a.model, vq, a.model, None, compute_dtype=dtype).to(dev)
+    if model.encoder.config.hidden_size != vq.e_dim:
+        raise SystemExit("model hidden size must equal the codebook dimension")
+    model.set_mode(a.mode)
+    model.train()                      # the reference trains with dropout on (Trainer.py:310)
+    ddp.broadcast_parameters(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=0.0, amsgrad=False, fused=True)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10000, 20000], gamma=0.1)
+    sync = ddp.GradSync(params, bucket_mib=a.bucket_mib) if world > 1 else None
+
+    # synthetic dSentences-like ids, resident in HBM before the timed region (BASELINE.md §3 recipe)
+    gen = torch.Generator().manual_seed(69 + rank)
+    pool = [tuple(t.to(dev) for t in random_token_batch(a.batch, a.seq_len, gen)) for _ in range(8)]
+
+    def one_step(i):
+        ids, mask = pool[i % len(pool)]
+        loss_vq, perp, _idx, loss_recon, acc, _recon = model.forward_loss(ids, mask)
+        loss = loss_recon + loss_vq
+        if sync is not None:
+            sync.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=False)
+        loss.backward()
+        if sync is not None:
+            sync.finish()
+        opt.step()
+        sched.step()
+        return loss
+
+    for i in range(a.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    lib.kvq_prof_enable(a.steps + 4)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = one_step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    final_loss = float(loss)
+
+    buf = (ctypes.c_float * (a.steps + 4))()
+    n_ev = lib.kvq_prof_read(buf, a.steps + 4)
+    lib.kvq_prof_enable(0)
+    vq_ms = sorted(buf[i] for i in range(n_ev))
+    vq_avg_ms = sum(vq_ms) / max(len(vq_ms), 1) if vq_ms else float("nan")
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        N_tok = a.batch * a.seq_len
+        D = vq.e_dim
+        es = 2 if dtype == torch.bfloat16 else 4
+        flops = 2.0 * N_tok * a.codes * D                                      # distance contraction
+        alg_bytes = N_tok * (2 * D * es + 8) + a.codes * D * 4                  # read z, write z_q, write idx, codebook once
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "vq_fwd_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"N{N_tok}_K{a.codes}_D{D}_{a.dtype}")
+            except Exception:
+                traffic = None
+        ach_tflops = flops / (vq_avg_ms * 1e-3) / 1e12 if vq_ms else None
+        out = {
+            "metric": "dSentences train sentences/sec",
+            "value": world * a.batch * a.steps / elapsed,
+            "unit": "sentences/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "config": {"workload": f"Bagon VQ (Shelgon) {a.model} enc/dec, K={a.codes} D={D} seq_len={a.seq_len} "
+                                   f"batch={a.batch}/GPU, mode={a.mode}, Adam, dropout on",
+                       "global_batch": world * a.batch, "seq_len": a.seq_len, "parallelism": f"dp{world}"},
+            "final_loss": final_loss,
+            "roofline": {
+                "kernel": "vq_fwd_mfma_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": (ach_tflops / F32_MFMA_PEAK_TFLOPS) if ach_tflops else None,
+                "traffic": traffic, "avg_launch_us": vq_avg_ms * 1e3 if vq_ms else None, "launches": len(vq_ms),
+                "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                "hbm": {"achieved": alg_bytes / (vq_avg_ms * 1e-3) / 1e9 if vq_ms else None, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": alg_bytes / (vq_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if vq_ms else None},
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import step_oracle
+            cfg = dict(BERT_BASE) if a.model == "bert-base-uncased" else None
+            if cfg is None:
+                from models.bagon.Bagon import LOCAL_BERT_CONFIGS
+                cfg = dict(LOCAL_BERT_CONFIGS[a.model])
+            cores = os.cpu_count() or 1
+            r = step_oracle.time_cpu_steps(cfg, batch=8, seq_len=a.seq_len, n_e=a.codes, e_dim=D, beta=0.25,
+                                           vocab_size=model.decoder.config.vocab_size, warmup=1, steps=a.cpu_steps,
+                                           threads=cores)
+            out["cpu_baseline"] = {"value": r["sentences_per_s"], "unit": "sentences/s", "cores": r["threads"], "kind": "port",
+                                   "sample": f"{a.cpu_steps} timed steps (median) of oracle/step_oracle.py at batch=8 seq_len={a.seq_len} "
+                                             f"f32 (BASELINE.json configs[0]), {r['s_per_step']:.2f} s/step"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

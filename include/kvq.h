@@ -99,6 +99,14 @@ int kvq_vq_one_hot(const int64_t* idx, int64_t N, int K, float* enc, void* strea
 int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int D, int io_dtype,
                            int use_mfma, float* d, void* stream);
 
+/* Kernel timing hook for bench.py's roofline line.  While enabled, every kvq_vq_forward call brackets its FUSED
+ * kernel (not the memset / finalize launches) with a pair of HIP events recorded on the call's stream.
+ *   kvq_prof_enable(n) : n > 0 allocates a ring of n event pairs and starts recording; n == 0 stops and frees.
+ *   kvq_prof_read(ms, max) : after the caller has synchronised the stream, writes up to `max` durations in
+ *                            milliseconds (oldest first), clears the ring and returns how many were written. */
+int kvq_prof_enable(int n_pairs);
+int kvq_prof_read(float* ms_host, int max);
+
 /* Which path kvq_vq_forward takes for a shape: 1 = f32-MFMA LDS-tiled kernel, 0 = generic kernel. */
 int kvq_vq_uses_mfma(int64_t N, int K, int D);
 

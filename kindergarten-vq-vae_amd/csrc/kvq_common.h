@@ -12,6 +12,9 @@ namespace kvq {
 // ---- error reporting (thread-local message, C-ABI never throws) -------------------------------------------
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+// profiling ring (kvq_prof_enable): record a start/stop event pair around one launch
+bool prof_begin(hipStream_t st);
+void prof_end(hipStream_t st);
 
 #define KVQ_REQUIRE(cond, ...)                                  \
     do {                                                        \

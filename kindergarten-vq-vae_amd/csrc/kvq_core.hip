@@ -21,9 +21,52 @@ int check_launch(const char* what) {
     return KVQ_OK;
 }
 
+// ---- profiling ring -----------------------------------------------------------------------------------------
+static hipEvent_t* g_ev = nullptr;   // 2*g_cap events: [start0, stop0, start1, stop1, ...]
+static int g_cap = 0, g_count = 0;
+
+bool prof_begin(hipStream_t st) {
+    if (!g_ev || g_count >= g_cap) return false;
+    (void)hipEventRecord(g_ev[2 * g_count], st);
+    return true;
+}
+void prof_end(hipStream_t st) {
+    (void)hipEventRecord(g_ev[2 * g_count + 1], st);
+    ++g_count;
+}
+
 }  // namespace kvq
 
 extern "C" {
+
+int kvq_prof_enable(int n_pairs) {
+    using namespace kvq;
+    if (g_ev) {
+        for (int i = 0; i < 2 * g_cap; ++i) (void)hipEventDestroy(g_ev[i]);
+        delete[] g_ev;
+        g_ev = nullptr;
+    }
+    g_cap = g_count = 0;
+    if (n_pairs <= 0) return KVQ_OK;
+    g_ev = new hipEvent_t[2 * (size_t)n_pairs];
+    for (int i = 0; i < 2 * n_pairs; ++i)
+        if (hipEventCreate(&g_ev[i]) != hipSuccess) return fail(KVQ_E_LAUNCH, "hipEventCreate failed");
+    g_cap = n_pairs;
+    return KVQ_OK;
+}
+
+int kvq_prof_read(float* ms_host, int max) {
+    using namespace kvq;
+    int n = 0;
+    for (; n < g_count && n < max; ++n) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_ev[2 * n], g_ev[2 * n + 1]) != hipSuccess)
+            return fail(KVQ_E_LAUNCH, "kvq_prof_read: events not complete (synchronise the stream first)");
+        ms_host[n] = ms;
+    }
+    g_count = 0;
+    return n;
+}
 
 int kvq_version(void) { return KVQ_VERSION; }
 

@@ -544,7 +544,9 @@ static int launch_forward(FwdParams p, int G, bool use_mfma, hipStream_t st) {
             attr_done[DT] = true;
         }
         dim3 grid((unsigned)((p.N + TM - 1) / TM), (unsigned)G);
+        const bool prof = prof_begin(st);
         hipLaunchKernelGGL(vq_fwd_mfma_kernel<DT>, grid, dim3(NTHREADS), LDS_BYTES, st, p);
+        if (prof) prof_end(st);
         return check_launch("vq_fwd_mfma_kernel");
     }
     const int64_t rows = (int64_t)G * p.K;

@@ -20,6 +20,8 @@ SIGNATURES = {
     "kvq_version": (_int, []),
     "kvq_last_error": (C.c_char_p, []),
     "kvq_device_info": (_int, [C.POINTER(_int), C.c_char_p, _sz]),
+    "kvq_prof_enable": (_int, [_int]),
+    "kvq_prof_read": (_int, [C.POINTER(C.c_float), _int]),
     "kvq_vq_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "kvq_vq_uses_mfma": (_int, [_i64, _int, _int]),
     "kvq_vq_forward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1,0 +1,159 @@
+"""Bagon -- BERT encoder -> BERT decoder (cross-attending) sentence autoencoder, MI355X execution.
+
+Surface kept from the reference (models/bagon/Bagon.py:15-179): constructor arguments, `.encoder` (BertModel) /
+`.decoder` (BertLMHeadModel with is_decoder + cross-attention) attributes and their state-dict keys,
+`forward(encoder_input_ids, encoder_attention_mask, decoder_input_ids, decoder_attention_mask) -> logits`,
+`set_mode`, `model_params_summary_{dict,print}`.
+
+Differences by design:
+  * model names are resolved OFFLINE: a local directory is loaded with from_pretrained, a known name
+    ("bert-base-uncased", ...) is built from its architecture config with random init -- the reference fetches
+    weights by name (Bagon.py:25-27), there is no network here;
+  * forward runs kvq.bert's fused plan in bf16 (f32 master weights) instead of HF's module-by-module forward;
+    `backend="hf"` keeps HF's own forward reachable (it is the oracle in tests/test_bert_parity.py).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from common.consts import COLOR_FROZEN, COLOR_TOT, COLOR_TRAIN
+from common.model_utils import n_not_trainable_params, n_params, n_trainable_params, print_module_params_summary
+from kvq import bert as kbert
+
+SUPPORTED_MODEL_MODES = ["full", "dec-head-ft", "enc-head-ft-dec-head-ft", "vq-ft"]
+
+# architecture of the names the reference uses; extra tiny entries are for tests / smoke
+LOCAL_BERT_CONFIGS = {
+    "bert-base-uncased": dict(),   # BertConfig() defaults ARE bert-base: 768/12/12/3072, vocab 30522, 512 positions
+    "kvq-bert-small": dict(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024),
+    "kvq-bert-tiny": dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                          vocab_size=2048, max_position_embeddings=64),
+}
+
+
+def build_bert_pair(encoder_model_name: str, decoder_model_name: str):
+    """What EncoderDecoderModel.from_encoder_decoder_pretrained(enc, dec) yields (Bagon.py:25-31), offline:
+    encoder = BertModel, decoder = BertLMHeadModel(is_decoder=True, add_cross_attention=True)."""
+    from transformers import BertConfig, BertLMHeadModel, BertModel
+
+    def cfg_of(name, **extra):
+        if os.path.isdir(name):
+            return BertConfig.from_pretrained(name, **extra), name
+        if name not in LOCAL_BERT_CONFIGS:
+            raise ValueError(f"unknown model name {name!r}: give a local directory or one of {sorted(LOCAL_BERT_CONFIGS)} "
+                             f"(no network: names cannot be fetched)")
+        return BertConfig(**LOCAL_BERT_CONFIGS[name], **extra), None
+
+    ecfg, edir = cfg_of(encoder_model_name)
+    dcfg, ddir = cfg_of(decoder_model_name, is_decoder=True, add_cross_attention=True)
+    encoder = BertModel.from_pretrained(edir, config=ecfg) if edir else BertModel(ecfg)
+    decoder = BertLMHeadModel.from_pretrained(ddir, config=dcfg) if ddir else BertLMHeadModel(dcfg)
+    return encoder, decoder
+
+
+class Bagon(nn.Module):
+    def __init__(self, encoder_model_name: str, decoder_model_name: str, cross_attn_make_trainable: bool = False,
+                 compute_dtype: torch.dtype = torch.bfloat16, backend: str = "kvq"):
+        super().__init__()
+        self.encoder, self.decoder = build_bert_pair(encoder_model_name, decoder_model_name)
+        self.encoder_model_name = encoder_model_name
+        self.decoder_model_name = decoder_model_name
+        self.cross_attn_make_trainable = cross_attn_make_trainable
+        self.compute_dtype = compute_dtype
+        self.backend = backend
+        self.model_mode = "full"
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def encode(self, input_ids, attention_mask):
+        if self.backend == "hf":
+            return self.encoder(input_ids, attention_mask=attention_mask).last_hidden_state
+        return kbert.encoder_forward(self.encoder, input_ids, attention_mask, self.compute_dtype)
+
+    def decode_hidden(self, encoder_hidden_states, input_ids, attention_mask):
+        """768-d prediction-head states; pair with `kvq.fused_cross_entropy(lm logits)` to avoid [N,V] temporaries."""
+        return kbert.decoder_hidden_forward(self.decoder, input_ids, attention_mask, encoder_hidden_states, self.compute_dtype)
+
+    def decode(self, encoder_hidden_states, input_ids, attention_mask):
+        if self.backend == "hf":
+            return self.decoder(encoder_hidden_states=encoder_hidden_states, input_ids=input_ids,
+                                attention_mask=attention_mask).logits
+        return kbert.decoder_forward(self.decoder, input_ids, attention_mask, encoder_hidden_states, self.compute_dtype)
+
+    def forward(self, encoder_input_ids, encoder_attention_mask, decoder_input_ids, decoder_attention_mask):
+        encoder_output = self.encode(encoder_input_ids, encoder_attention_mask)            # Bagon.py:46-48
+        return self.decode(encoder_output, decoder_input_ids, decoder_attention_mask)      # Bagon.py:50-55
+
+    def forward_loss(self, encoder_input_ids, encoder_attention_mask, decoder_input_ids, decoder_attention_mask):
+        """Fused step body of the plain autoencoder: (loss_recon, acc_per_batch, recon_ids) -- the loss block of
+        models/bagon/Trainer.py:103-110 in one pass over the logits."""
+        from kvq.functional import fused_cross_entropy
+        enc = self.encode(encoder_input_ids, encoder_attention_mask)
+        hidden = self.decode_hidden(enc, decoder_input_ids, decoder_attention_mask)
+        logits = kbert.lm_head_logits(self.decoder, hidden, self.compute_dtype)
+        return fused_cross_entropy(logits, decoder_input_ids, inplace_backward=True)
+
+    # ---- bookkeeping ---------------------------------------------------------------------------------------------
+    def _summary_parts(self):
+        return [("encoder", "Encoder", self.encoder), ("decoder", "Decoder", self.decoder)]
+
+    def model_params_summary_dict(self):
+        return {key: {"n_trainable_params": n_trainable_params(m), "n_not_trainable_params": n_not_trainable_params(m),
+                      "n_params": n_params(m)} for key, _, m in self._summary_parts()}
+
+    def model_params_summary_print(self):
+        for _, title, m in self._summary_parts():
+            print_module_params_summary(m, title, COLOR_TRAIN, COLOR_FROZEN, COLOR_TOT)
+
+    # ---- trainability modes (Bagon.py:87-179) ---------------------------------------------------------------------
+    @staticmethod
+    def _module_make_trainable(module, flag: bool):
+        for p in module.parameters():
+            p.requires_grad = flag
+
+    def _encoder_make_trainable(self, flag: bool):
+        self._module_make_trainable(self.encoder, flag)
+
+    def _decoder_make_trainable(self, flag: bool):
+        self._module_make_trainable(self.decoder, flag)
+
+    def _decoder_lm_head_make_trainable(self, flag: bool):
+        # decoder.cls.predictions.{transform.dense, decoder}; the latter's weight is TIED to the decoder word
+        # embeddings, so the embedding table trains in dec-head-ft mode too
+        head = self.decoder.cls.predictions
+        self._module_make_trainable(head.transform.dense, flag)
+        self._module_make_trainable(head.decoder, flag)
+
+    def _decoder_cross_attn_make_trainable(self, flag: bool):
+        for layer in self.decoder.bert.encoder.layer:
+            self._module_make_trainable(layer.crossattention, flag)
+
+    def _set_mode_dec_head_ft(self):
+        self.model_mode = "dec-head-ft"
+        self._encoder_make_trainable(False)
+        self._decoder_make_trainable(False)
+        self._decoder_lm_head_make_trainable(True)
+        self._decoder_cross_attn_make_trainable(self.cross_attn_make_trainable)
+
+    def _set_mode_enc_head_dec_head_ft(self):
+        self._set_mode_dec_head_ft()
+        self.model_mode = "enc-dec-head-ft"
+        self._module_make_trainable(self.encoder.encoder.layer[-1], True)
+        if self.encoder.pooler is not None:
+            self._module_make_trainable(self.encoder.pooler, True)
+
+    def set_mode(self, model_mode: str):
+        if model_mode == "full":
+            self.model_mode = "full"
+        elif model_mode == "dec-head-ft":
+            self._set_mode_dec_head_ft()
+        elif model_mode == "enc-head-ft-dec-head-ft":
+            self._set_mode_enc_head_dec_head_ft()
+        elif model_mode == "vq-ft":
+            self.model_mode = "vq-ft"
+            self._encoder_make_trainable(False)
+            self._decoder_make_trainable(False)
+        else:
+            raise ValueError(f"Invalid model mode {model_mode}, please use one of the following: {', '.join(SUPPORTED_MODEL_MODES)}")

@@ -1,0 +1,99 @@
+"""TEST INFRASTRUCTURE -- CPU (f32, PyTorch ATen) restatement of one training step of the reference's VQ run.
+
+Used only by tests/ and by bench.py's cpu_baseline leg ("port": timed on the GPU box's host cores).
+Follows, expression for expression:
+    models/shelgon3/Shelgon.py:50-73   encoder -> VectorQuantizer -> decoder(encoder_hidden_states=z_q).logits
+    models/shelgon3/Trainer.py:82-115  pad to max_length, kl_div(log_softmax, one_hot) "batchmean", argmax(softmax),
+                                       seq_acc, weighted sum, zero_grad / backward / Adam step / scheduler tick
+    models/shelgon3/main.py:91         Adam over ALL model.parameters()
+The BERT blocks are HuggingFace's own classes (third-party part of the reference, transformers 5.15 in this image)
+built from a local BertConfig: encoder = BertModel, decoder = BertLMHeadModel(is_decoder, add_cross_attention)
+(what EncoderDecoderModel.from_encoder_decoder_pretrained builds, Bagon.py:24-31).
+Parity status: the VQ part is pinned by tests/golden; the composition has no reference-side fixture (the reference's
+Shelgon/Trainer do not import as checked in) -> "parity unpinned" for the composed step, stated in DESIGN.md.
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+import torch.nn as nn
+from torch.nn.functional import kl_div, log_softmax, one_hot, softmax
+
+from .vq_oracle import torch_expr_forward
+
+
+class OracleVQ(nn.Module):
+    """VectorQuantizer.py:19-29 parameters + :31-93 forward (via torch_expr_forward)."""
+
+    def __init__(self, n_e, e_dim, beta, init=None):
+        super().__init__()
+        self.n_e, self.e_dim, self.beta = n_e, e_dim, beta
+        self.embedding = nn.Embedding(n_e, e_dim)
+        if init is not None:
+            self.embedding.weight.data.copy_(init)
+        else:
+            self.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)
+
+    def forward(self, z, device=None):
+        return torch_expr_forward(z, self.embedding.weight, self.beta)
+
+
+class OracleShelgon(nn.Module):
+    def __init__(self, bert_cfg: dict, n_e=512, e_dim=768, beta=0.25, codebook_init=None):
+        super().__init__()
+        from transformers import BertConfig, BertLMHeadModel, BertModel
+        self.encoder = BertModel(BertConfig(**bert_cfg))
+        self.decoder = BertLMHeadModel(BertConfig(**bert_cfg, is_decoder=True, add_cross_attention=True))
+        self.vector_quantizer = OracleVQ(n_e, e_dim, beta, codebook_init)
+
+    def forward(self, input_ids, attention_mask):
+        embeds = self.encoder(input_ids, attention_mask=attention_mask).last_hidden_state          # Shelgon.py:52
+        vq_loss, z_q, perplexity, _enc, idx = self.vector_quantizer(embeds)                          # Shelgon.py:58
+        logits = self.decoder(encoder_hidden_states=z_q, input_ids=input_ids, attention_mask=attention_mask).logits  # :71
+        return vq_loss, perplexity, idx, logits
+
+
+def step(model, opt, input_ids, attention_mask, vocab_size, w_recon=1.0, w_vq=1.0, lr_sched=None):
+    """Trainer.py:87-124 (tokenisation happens upstream: ids are given)."""
+    loss_vq, perp, idx, logits = model(input_ids, attention_mask)
+    loss_recon = kl_div(input=log_softmax(logits.reshape(-1, vocab_size), dim=-1),
+                        target=one_hot(input_ids, vocab_size).reshape(-1, vocab_size).float(), reduction="batchmean")
+    recon_ids = torch.argmax(softmax(logits, dim=-1), dim=-1)
+    acc = (recon_ids == input_ids).sum() / input_ids.numel()                                          # common/metrics.py:25-30
+    loss_recon = loss_recon * w_recon
+    loss_vq = loss_vq * w_vq
+    loss_full = loss_recon + loss_vq
+    if opt is not None:
+        opt.zero_grad()
+        loss_full.backward()
+        opt.step()
+        if lr_sched is not None:
+            lr_sched.step()
+    return dict(loss_recon=loss_recon.detach(), loss_vq=loss_vq.detach(), perplexity=perp.detach(), loss_full=loss_full.detach(),
+                acc=acc, idx=idx, recon_ids=recon_ids)
+
+
+def time_cpu_steps(bert_cfg: dict, batch: int, seq_len: int, n_e: int, e_dim: int, beta: float, vocab_size: int,
+                   warmup: int, steps: int, seed: int = 0, threads: int | None = None):
+    """CPU baseline for bench.py: sentences/s of the restated step on this host's cores (f32, train mode, Adam on all params)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kindergarten-vq-vae_amd"))
+    from dsentences.synthetic import random_token_batch
+    if threads:
+        torch.set_num_threads(threads)
+    torch.manual_seed(seed)
+    model = OracleShelgon(bert_cfg, n_e, e_dim, beta).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    gen = torch.Generator().manual_seed(69)
+    times = []
+    for i in range(warmup + steps):
+        ids, mask = random_token_batch(batch, seq_len, gen)
+        t0 = time.perf_counter()
+        step(model, opt, ids, mask, vocab_size)
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(sentences_per_s=batch / med, s_per_step=med, threads=torch.get_num_threads(), steps=steps, batch=batch)
