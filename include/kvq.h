@@ -110,6 +110,11 @@ int kvq_prof_read(float* ms_host, int max);
 /* Which path kvq_vq_forward takes for a shape: 1 = f32-MFMA LDS-tiled kernel, 0 = generic kernel. */
 int kvq_vq_uses_mfma(int64_t N, int K, int D);
 
+/* Tuning / A-B switch between the two MFMA forward structures (both bit-identical in results):
+ *   2 (default) = 2-D tiled distance kernel (32 tokens x 128 codes per workgroup, 4 workgroups per CU, 64-bit
+ *                 atomicMin hand-over) + streaming epilogue kernel;   1 = single fused kernel (32 tokens x all codes). */
+int kvq_vq_set_forward_variant(int variant);
+
 /* EMA codebook update (extension named by BASELINE.json north_star; NOT in the reference -> default off):
  *   n_k <- g*n_k + (1-g)*count_k ;  m_k <- g*m_k + (1-g)*sum_{idx_n=k} z_n ;
  *   E_k <- m_k / ((n_k + eps)/(sum n + K*eps) * sum n)

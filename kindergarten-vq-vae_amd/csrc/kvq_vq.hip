@@ -50,6 +50,7 @@ struct FwdParams {
     unsigned* counts;   // ws [G,K]
     const float* e2;    // ws [G,K]  (generic path only)
     float* dump;        // optional [N,K] distances (debug hook), G == 1
+    unsigned long long* keys;  // ws [G,N]  (v2 path: packed (distance, code) minima)
     int64_t N;
     int K, D;
 };
@@ -58,7 +59,7 @@ struct FwdParams {
 // per-token epilogue, executed by one full wave: gather, straight-through, squared error, histogram
 //   VectorQuantizer.py:72 (z_q = E[idx]), :76-77 (squared error), :80 (z + (z_q - z))
 // -------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, bool HIST>
 __device__ __forceinline__ void token_epilogue(const FwdParams& p, int g, int64_t tok, int code, int lane) {
     const size_t zrow = ((size_t)g * p.N + (size_t)tok) * p.D;
     const float* e = p.E + ((size_t)g * p.K + (size_t)code) * p.D;
@@ -85,7 +86,7 @@ __device__ __forceinline__ void token_epilogue(const FwdParams& p, int g, int64_
     if (lane == 0) {
         p.tok_sumsq[(size_t)g * p.N + tok] = ss;
         p.idx[(size_t)g * p.N + tok] = (int64_t)code;
-        atomicAdd(p.counts + (size_t)g * p.K + code, 1u);   // integer histogram: order independent, exact
+        if (HIST) atomicAdd(p.counts + (size_t)g * p.K + code, 1u);   // integer histogram: order independent, exact
     }
 }
 
@@ -234,13 +235,208 @@ __global__ __launch_bounds__(NTHREADS) void vq_fwd_mfma_kernel(FwdParams p) {
         fin_idx[tid] = bi;
     }
     __syncthreads();
+    // histogram: one atomic per DISTINCT code of this workgroup's 32 tokens (a collapsed codebook would otherwise
+    // send every token's atomic to the same address, which serialises at the memory side)
+    if (tid < TM && tok0 + tid < p.N) {
+        const int c = fin_idx[tid];
+        unsigned cnt = 0;
+        bool first = true;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const bool same = (tok0 + j < p.N) && fin_idx[j] == c;
+            cnt += same ? 1u : 0u;
+            first = first && !(same && j < tid);
+        }
+        if (first) atomicAdd(p.counts + (size_t)g * p.K + c, cnt);
+    }
 
     // ---- epilogue: each wave finishes 4 tokens
 #pragma unroll 1
     for (int t = 0; t < TM / NWAVES; ++t) {
         const int ti = w * (TM / NWAVES) + t;
         const int64_t tok = tok0 + ti;
-        if (tok < p.N) token_epilogue<DT>(p, g, tok, fin_idx[ti], lane);
+        if (tok < p.N) token_epilogue<DT, false>(p, g, tok, fin_idx[ti], lane);
+    }
+}
+
+// =============================================================================================================
+// v2 fast path: 2-D tiled distance/argmin kernel + streaming epilogue kernel
+//
+//   grid (N/32, K/128, G), 256 threads = 4 waves (one per SIMD), 40 KiB LDS  ->  4 workgroups per CU whose
+//   waves are NOT barrier-coupled to each other: while one workgroup waits on its stage hand-over, the other
+//   three keep the SIMD's matrix pipe busy.  Each workgroup owns 32 tokens x 128 codes over the whole contraction
+//   (24 stages of 32 floats; rows are 128 B, 16-byte chunks swizzled by ((row >> 1) & 7) -> conflict-free
+//   ds_read_b128).  Its per-token minimum goes to global memory as ONE 64-bit atomicMin per token on the key
+//   (orderable(d) << 32 | code): minimum distance first, lowest code on ties, NaN mapped to key 0 (torch.argmin).
+//   The epilogue kernel (HBM-bound) decodes the keys: gather, straight-through, squared error, histogram.
+// =============================================================================================================
+constexpr int T2_TM = 32;
+constexpr int T2_WAVES = 4;
+constexpr int T2_THREADS = T2_WAVES * WAVE;
+constexpr int T2_CN = T2_WAVES * 32;          // 128 codes per workgroup
+constexpr int T2_KC = 32;                     // floats per stage (128-byte rows)
+constexpr int T2_E_TILE = T2_CN * T2_KC;      // 4096 floats
+constexpr int T2_STAGE = (T2_CN + T2_TM) * T2_KC;   // 5120 floats = 20 KiB
+constexpr size_t T2_LDS_BYTES = 2 * T2_STAGE * sizeof(float);   // 40 KiB: four workgroups fill the CU's 160 KiB
+constexpr int T2_E_CHUNKS = (T2_CN * (T2_KC / 4)) / T2_THREADS;  // 4
+static_assert(T2_TM * (T2_KC / 4) == T2_THREADS, "one z chunk per thread per stage");
+
+__device__ __forceinline__ unsigned long long pack_key(float d, int code) {
+    unsigned u = __float_as_uint(d);
+    unsigned key = (d != d) ? 0u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));   // monotone map, NaN lowest
+    return ((unsigned long long)key << 32) | (unsigned)code;
+}
+
+template <int DT>
+__device__ __forceinline__ void t2_issue(const FwdParams& p, const float* __restrict__ E, size_t zbase, int64_t tok0,
+                                         int code0, int kc, int tid, f32x4 (&er)[T2_E_CHUNKS], f32x4& zr) {
+#pragma unroll
+    for (int q = 0; q < T2_E_CHUNKS; ++q) {
+        const int L = q * T2_THREADS + tid;
+        const int r = L >> 3, c = L & 7;
+        int code = code0 + r;
+        code = code < p.K ? code : p.K - 1;
+        er[q] = *reinterpret_cast<const f32x4*>(E + (size_t)code * p.D + kc * T2_KC + c * 4);
+    }
+    const int r = tid >> 3, c = tid & 7;
+    const int64_t tok = tok0 + r;
+    f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    zr = tok < p.N ? IO<DT>::load4(p.z, zbase + (size_t)tok * p.D + kc * T2_KC + c * 4) : zero;
+}
+
+__device__ __forceinline__ void t2_commit(float* sb, int tid, const f32x4 (&er)[T2_E_CHUNKS], const f32x4& zr) {
+#pragma unroll
+    for (int q = 0; q < T2_E_CHUNKS; ++q) {
+        const int L = q * T2_THREADS + tid;
+        const int r = L >> 3, c = L & 7;
+        *reinterpret_cast<f32x4*>(sb + r * T2_KC + ((c ^ ((r >> 1) & 7)) << 2)) = er[q];
+    }
+    const int r = tid >> 3, c = tid & 7;
+    *reinterpret_cast<f32x4*>(sb + T2_E_TILE + r * T2_KC + ((c ^ ((r >> 1) & 7)) << 2)) = zr;
+}
+
+template <int DT>
+__global__ __launch_bounds__(T2_THREADS, 4) void vq_dist_tile_kernel(FwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int g = blockIdx.z;
+    const int64_t tok0 = (int64_t)blockIdx.x * T2_TM;
+    const int code0 = blockIdx.y * T2_CN;
+    const float* __restrict__ E = p.E + (size_t)g * p.K * p.D;
+    const size_t zbase = (size_t)g * p.N * p.D;
+    const int nst = p.D / T2_KC;
+
+    f32x4 er[T2_E_CHUNKS];
+    f32x4 zr;
+    t2_issue<DT>(p, E, zbase, tok0, code0, 0, tid, er, zr);
+    t2_commit(smem, tid, er, zr);
+    __syncthreads();
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float pe = 0.f, pz = 0.f;
+    const int sw = (i >> 1) & 7;
+
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nst;
+        if (more) t2_issue<DT>(p, E, zbase, tok0, code0, st + 1, tid, er, zr);
+        const float* sb = smem + buf * T2_STAGE;
+        const float* erow = sb + (w * 32 + i) * T2_KC;
+        const float* zrow = sb + T2_E_TILE + i * T2_KC;
+#pragma unroll
+        for (int gq = 0; gq < T2_KC / 8; ++gq) {
+            const int slot = ((2 * gq + h) ^ sw) << 2;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(erow + slot);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(zrow + slot);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            pe = __builtin_fmaf(a.x, a.x, pe); pe = __builtin_fmaf(a.y, a.y, pe);
+            pe = __builtin_fmaf(a.z, a.z, pe); pe = __builtin_fmaf(a.w, a.w, pe);
+            pz = __builtin_fmaf(b.x, b.x, pz); pz = __builtin_fmaf(b.y, b.y, pz);
+            pz = __builtin_fmaf(b.z, b.z, pz); pz = __builtin_fmaf(b.w, b.w, pz);
+        }
+        if (more) t2_commit(smem + (buf ^ 1) * T2_STAGE, tid, er, zr);
+        __syncthreads();
+    }
+
+    // distances of this wave's 32 codes x 32 tokens; lane-local minimum over its 16 codes
+    const float z2 = pz + __shfl_xor(pz, 32, WAVE);
+    const float e2v = pe + __shfl_xor(pe, 32, WAVE);
+    const int cbase = code0 + w * 32;
+    float best = INFINITY;
+    int bidx = INT_MAX;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float e2r = __shfl(e2v, cl, WAVE);
+        const float t = z2 + e2r;
+        const float dd = t - 2.0f * acc[r];
+        const int code = cbase + cl;
+        if (code < p.K) {
+            if (p.dump && tok0 + i < p.N) p.dump[(size_t)(tok0 + i) * p.K + code] = dd;
+            if (cand_better(dd, code, best, bidx)) { best = dd; bidx = code; }
+        }
+    }
+    {
+        const float ob = __shfl_xor(best, 32, WAVE);
+        const int oi = __shfl_xor(bidx, 32, WAVE);
+        if (cand_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
+    }
+    // the stage buffers are dead (every wave passed the loop's last barrier): reuse them for the 4-wave merge
+    float* red_val = smem;
+    int* red_idx = reinterpret_cast<int*>(smem + T2_WAVES * T2_TM);
+    if (lane < 32) {
+        red_val[w * T2_TM + i] = best;
+        red_idx[w * T2_TM + i] = bidx;
+    }
+    __syncthreads();
+    if (tid < T2_TM && tok0 + tid < p.N) {
+        float b = red_val[tid];
+        int bi = red_idx[tid];
+#pragma unroll
+        for (int ww = 1; ww < T2_WAVES; ++ww) {
+            const float v = red_val[ww * T2_TM + tid];
+            const int vi = red_idx[ww * T2_TM + tid];
+            if (cand_better(v, vi, b, bi)) { b = v; bi = vi; }
+        }
+        if (bi != INT_MAX) atomicMin(p.keys + (size_t)g * p.N + tok0 + tid, pack_key(b, bi));
+    }
+}
+
+// epilogue of the v2 path: 64 tokens per workgroup, one wave per token at a time
+constexpr int EP_TOK = 64;
+constexpr int EP_THREADS = 256;
+
+template <int DT>
+__global__ __launch_bounds__(EP_THREADS) void vq_epilogue_kernel(FwdParams p) {
+    __shared__ int codes[EP_TOK];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int g = blockIdx.y;
+    const int64_t tok0 = (int64_t)blockIdx.x * EP_TOK;
+    if (tid < EP_TOK) {
+        const int64_t tok = tok0 + tid;
+        codes[tid] = tok < p.N ? (int)(unsigned)(p.keys[(size_t)g * p.N + tok] & 0xffffffffull) : -1;
+    }
+    __syncthreads();
+    if (tid < EP_TOK && codes[tid] >= 0) {       // one histogram atomic per distinct code of the workgroup
+        const int c = codes[tid];
+        unsigned cnt = 0;
+        bool first = true;
+        for (int j = 0; j < EP_TOK; ++j) {
+            const bool same = codes[j] == c;
+            cnt += same ? 1u : 0u;
+            first = first && !(same && j < tid);
+        }
+        if (first) atomicAdd(p.counts + (size_t)g * p.K + c, cnt);
+    }
+    for (int t = w; t < EP_TOK; t += EP_THREADS / WAVE) {
+        const int64_t tok = tok0 + t;
+        if (tok < p.N) token_epilogue<DT, false>(p, g, tok, codes[t], lane);
     }
 }
 
@@ -312,7 +508,7 @@ __global__ __launch_bounds__(GEN_WAVES* WAVE) void vq_fwd_generic_kernel(FwdPara
         const int oi = __shfl_xor(bidx, m, WAVE);
         if (cand_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
     }
-    token_epilogue<DT>(p, g, tok, bidx, lane);
+    token_epilogue<DT, true>(p, g, tok, bidx, lane);
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -366,6 +562,7 @@ struct BwdParams {
     void* g_z;
     float* g_E;
     float* slab;   // ws [G,T,K,D]
+    int* slab_cnt; // ws [G,T,K]
     int64_t N;
     int K, D, T;
     int64_t chunk;  // tokens per chunk (multiple of 64)
@@ -405,51 +602,78 @@ __global__ __launch_bounds__(256) void vq_bwd_gz_kernel(BwdParams p) {
     }
 }
 
-// slab[t][k][:] = sum over tokens n of chunk t with idx_n == k, in increasing n, of f(n)
+// slab[t][k][:] = sum over the tokens n of chunk t with idx_n == k, in increasing n, of f(n); cnt[t][k] = how many
 //   MODE 0: f = fl(e_k - z_n)   (codebook gradient)        MODE 1: f = z_n   (EMA cluster sums)
-// grid (K, T, G); each wave owns 64 float columns at a time; every wave scans the chunk's indices itself
-// (coalesced 64 at a time + ballot), so the visiting order is the token order: deterministic, no atomics.
+// grid (K, T, G), 256 threads.  Phase 1: the chunk's indices are scanned once (coalesced, ballot + prefix) into an
+// ORDERED list of matching tokens in LDS.  Phase 2: threads own columns and walk the list with independent,
+// unrolled row loads.  The visiting order is the token order: deterministic, no float atomics.
+constexpr int SEG_THREADS = 256;
+constexpr int SEG_MAX_CHUNK = 4096;   // tokens per chunk (LDS list capacity)
+
 template <int DT, int MODE>
-__global__ __launch_bounds__(256) void vq_seg_sum_kernel(BwdParams p) {
+__global__ __launch_bounds__(SEG_THREADS) void vq_seg_sum_kernel(BwdParams p) {
+    __shared__ int list[SEG_MAX_CHUNK];
+    __shared__ int wave_cnt[SEG_THREADS / WAVE];
+    __shared__ int base_s;
     const int k = blockIdx.x, t = blockIdx.y, g = blockIdx.z;
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t n0 = (int64_t)t * p.chunk;
     const int64_t n1 = n0 + p.chunk < p.N ? n0 + p.chunk : p.N;
     const int64_t* idx = p.idx + (size_t)g * p.N;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int64_t nb = n0; nb < n1; nb += SEG_THREADS) {      // uniform trip count for the whole workgroup
+        const int64_t n = nb + tid;
+        const bool hit = n < n1 && idx[n] == (int64_t)k;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_cnt[w] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int ww = 0; ww < w; ++ww) off += wave_cnt[ww];
+        if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)(n - n0);
+        __syncthreads();
+        if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    const int cnt = base_s;
+    if (tid == 0) p.slab_cnt[((size_t)g * p.T + t) * p.K + k] = cnt;
+    if (cnt == 0) return;
     const float* e = p.E ? p.E + ((size_t)g * p.K + k) * p.D : nullptr;
     float* out = p.slab + (((size_t)g * p.T + t) * p.K + k) * p.D;
-    // wave-uniform trip count (every lane of a wave takes part in each ballot); columns past D are masked
-    for (int j0 = (threadIdx.x & ~63); j0 < p.D; j0 += blockDim.x) {
-        const int j = j0 + lane;
-        const bool col = j < p.D;
+    const size_t zrow0 = ((size_t)g * p.N + (size_t)n0) * p.D;
+    for (int j = tid; j < p.D; j += SEG_THREADS) {
+        const float ej = (MODE == 0) ? e[j] : 0.f;
         float acc = 0.f;
-        const float ej = (MODE == 0 && col) ? e[j] : 0.f;
-        for (int64_t nb = n0; nb < n1; nb += WAVE) {
-            const int64_t n = nb + lane;
-            const bool hit = n < n1 && idx[n] == (int64_t)k;
-            unsigned long long m = __ballot(hit);
-            while (m) {
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const float zv = col ? IO<DT>::load1(p.z, ((size_t)g * p.N + (size_t)(nb + b)) * p.D + j) : 0.f;
-                acc += (MODE == 0) ? (ej - zv) : zv;
-            }
+        int i = 0;
+        for (; i + 8 <= cnt; i += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = IO<DT>::load1(p.z, zrow0 + (size_t)list[i + u] * p.D + j);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (MODE == 0) ? (ej - v[u]) : v[u];
         }
-        if (col) out[j] = acc;
+        for (; i < cnt; ++i) {
+            const float v = IO<DT>::load1(p.z, zrow0 + (size_t)list[i] * p.D + j);
+            acc += (MODE == 0) ? (ej - v) : v;
+        }
+        out[j] = acc;
     }
 }
 
-// g_E[k][:] = beta * s * sum_t slab[t][k][:]   (t in increasing order)
+// g_E[k][:] = beta * s * sum_t slab[t][k][:]   (t in increasing order; empty (t,k) cells are skipped, never read)
 __global__ void vq_bwd_combine_kernel(BwdParams p) {
     const int g = blockIdx.y;
     const size_t KD = (size_t)p.K * p.D;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= KD) return;
+    const int k = (int)(e / p.D);
     const float gl = p.g_loss ? p.g_loss[g] : 1.0f;
     const float s = (float)((double)gl * 2.0 / ((double)p.N * (double)p.D));
     const float* sl = p.slab + (size_t)g * p.T * KD + e;
+    const int* sc = p.slab_cnt + (size_t)g * p.T * p.K + k;
     float a = 0.f;
-    for (int t = 0; t < p.T; ++t) a += sl[(size_t)t * KD];
+    for (int t = 0; t < p.T; ++t)
+        if (sc[(size_t)t * p.K] > 0) a += sl[(size_t)t * KD];
     p.g_E[(size_t)g * KD + e] = (p.beta * s) * a;
 }
 
@@ -480,7 +704,7 @@ __global__ __launch_bounds__(256) void vq_ema_n_kernel(const unsigned* cnt, int 
     if (t == 0) tot_out[g] = sd[0];
 }
 
-__global__ void vq_ema_apply_kernel(const float* slab, int T, int K, int D, float decay, float eps,
+__global__ void vq_ema_apply_kernel(const float* slab, const int* slab_cnt, int T, int K, int D, float decay, float eps,
                                     const float* ema_n, const double* tot, float* ema_m, float* E) {
     const int g = blockIdx.y;
     const size_t KD = (size_t)K * D;
@@ -489,7 +713,8 @@ __global__ void vq_ema_apply_kernel(const float* slab, int T, int K, int D, floa
     const int k = (int)(e / D);
     const float* sl = slab + (size_t)g * T * KD + e;
     double sum = 0.0;
-    for (int t = 0; t < T; ++t) sum += (double)sl[(size_t)t * KD];
+    for (int t = 0; t < T; ++t)
+        if (slab_cnt[((size_t)g * T + t) * K + k] > 0) sum += (double)sl[(size_t)t * KD];
     const double tt = tot[g];
     const double nk = ((double)ema_n[(size_t)g * K + k] + (double)eps) / (tt + (double)K * (double)eps) * tt;
     const size_t i = (size_t)g * KD + e;
@@ -509,32 +734,53 @@ __global__ void vq_one_hot_kernel(const int64_t* __restrict__ idx, int64_t N, in
 // =============================================================================================================
 // host side
 // =============================================================================================================
-static int pick_T(int64_t N, int K) {
-    // ~2048 (code, chunk) workgroups; chunk a multiple of 64 tokens
-    int64_t T = 1;
-    while (T * K < 2048 && (N + T * 2 - 1) / (T * 2) >= 64) T *= 2;
+static int pick_T(int64_t N, int K, int D) {
+    // chunks of >= 256 tokens, as many as keep the slab [T,K,D] under 64 MiB; a chunk never exceeds SEG_MAX_CHUNK
+    int64_t T = (N + 255) / 256;
+    const int64_t cap = (64ll << 20) / ((int64_t)K * D * 4);
+    if (T > cap) T = cap;
+    const int64_t need = (N + SEG_MAX_CHUNK - 1) / SEG_MAX_CHUNK;
+    if (T < need) T = need;
+    if (T < 1) T = 1;
     return (int)T;
 }
-static int64_t chunk_of(int64_t N, int T) { return ((N + T - 1) / T + 63) / 64 * 64; }
+static int64_t chunk_of(int64_t N, int T) { return ((N + T - 1) / T + 255) / 256 * 256; }
 
 struct WsLayout {
-    size_t counts, sumsq, e2, slab, total;
+    size_t counts, sumsq, e2, keys, slab, slab_cnt, total;
 };
 static WsLayout ws_layout(int64_t N, int K, int D, int G) {
     WsLayout l;
     size_t off = 0;
+    const int T = pick_T(N, K, D);
     l.counts = off; off = align_up(off + (size_t)G * K * sizeof(unsigned), 256);
     l.sumsq = off;  off = align_up(off + (size_t)G * N * sizeof(double), 256);
     l.e2 = off;     off = align_up(off + (size_t)G * K * sizeof(float) + 16, 256);
-    l.slab = off;   off = align_up(off + (size_t)G * pick_T(N, K) * K * D * sizeof(float), 256);
+    l.keys = off;   off = align_up(off + (size_t)G * N * sizeof(unsigned long long), 256);
+    l.slab_cnt = off; off = align_up(off + (size_t)G * T * K * sizeof(int), 256);
+    l.slab = off;   off = align_up(off + (size_t)G * T * K * D * sizeof(float), 256);
     l.total = off;
     return l;
 }
 
-static bool mfma_ok(int64_t N, int K, int D) { return N > 0 && K > 0 && D > 0 && D % KC == 0; }
+static bool mfma_ok(int64_t N, int K, int D) { return N > 0 && K > 0 && D > 0 && D % T2_KC == 0; }
+static int g_fwd_variant = 2;   // 2 = tiled distance kernel + epilogue kernel; 1 = single fused kernel (needs D % 64 == 0)
 
 template <int DT>
 static int launch_forward(FwdParams p, int G, bool use_mfma, hipStream_t st) {
+    if (use_mfma && (g_fwd_variant == 2 || p.D % KC != 0)) {
+        hipError_t e = hipMemsetAsync(p.keys, 0xff, (size_t)G * p.N * sizeof(unsigned long long), st);
+        if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipMemsetAsync(keys): %s", hipGetErrorString(e));
+        dim3 grid((unsigned)((p.N + T2_TM - 1) / T2_TM), (unsigned)((p.K + T2_CN - 1) / T2_CN), (unsigned)G);
+        const bool prof = prof_begin(st);
+        hipLaunchKernelGGL(vq_dist_tile_kernel<DT>, grid, dim3(T2_THREADS), T2_LDS_BYTES, st, p);
+        if (prof) prof_end(st);
+        int rc = check_launch("vq_dist_tile_kernel");
+        if (rc) return rc;
+        dim3 egrid((unsigned)((p.N + EP_TOK - 1) / EP_TOK), (unsigned)G);
+        hipLaunchKernelGGL(vq_epilogue_kernel<DT>, egrid, dim3(EP_THREADS), 0, st, p);
+        return check_launch("vq_epilogue_kernel");
+    }
     if (use_mfma) {
         static bool attr_done[2] = {false, false};
         if (!attr_done[DT]) {
@@ -572,6 +818,12 @@ size_t kvq_vq_workspace_bytes(int64_t N, int K, int D, int G) {
 
 int kvq_vq_uses_mfma(int64_t N, int K, int D) { return mfma_ok(N, K, D) ? 1 : 0; }
 
+int kvq_vq_set_forward_variant(int variant) {
+    if (variant != 1 && variant != 2) return fail(KVQ_E_INVALID, "kvq_vq_set_forward_variant: 1 or 2, got %d", variant);
+    g_fwd_variant = variant;
+    return KVQ_OK;
+}
+
 int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G, int io_dtype, float beta,
                    void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts, void* ws,
                    size_t ws_bytes, void* stream) {
@@ -591,6 +843,7 @@ int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G
     p.tok_sumsq = (double*)(w + l.sumsq);
     p.counts = (unsigned*)(w + l.counts);
     p.e2 = (const float*)(w + l.e2);
+    p.keys = (unsigned long long*)(w + l.keys);
     p.dump = nullptr;
     p.N = N; p.K = K; p.D = D;
     hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)G * K * sizeof(unsigned), st);
@@ -620,6 +873,7 @@ int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int 
     FwdParams p;
     p.z = z; p.E = E; p.z_q = zq; p.idx = (int64_t*)ix;
     p.tok_sumsq = (double*)(w + l.sumsq); p.counts = (unsigned*)(w + l.counts); p.e2 = (const float*)(w + l.e2);
+    p.keys = (unsigned long long*)(w + l.keys);
     p.dump = d; p.N = N; p.K = K; p.D = D;
     (void)hipMemsetAsync(p.counts, 0, (size_t)K * sizeof(unsigned), st);
     int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, 1, use_mfma != 0, st)
@@ -641,7 +895,8 @@ int kvq_vq_backward(const void* z, const float* E, const int64_t* idx, const voi
     BwdParams p;
     p.z = z; p.E = E; p.idx = idx; p.g_zq = g_zq; p.g_loss = g_loss; p.g_z = g_z; p.g_E = g_E;
     p.slab = ws ? (float*)((char*)ws + l.slab) : nullptr;
-    p.N = N; p.K = K; p.D = D; p.T = pick_T(N, K); p.chunk = chunk_of(N, p.T); p.beta = beta;
+    p.N = N; p.K = K; p.D = D; p.T = pick_T(N, K, D); p.chunk = chunk_of(N, p.T); p.beta = beta;
+    p.slab_cnt = ws ? (int*)((char*)ws + l.slab_cnt) : nullptr;
     if (g_z) {
         dim3 grid((unsigned)((N + 3) / 4), (unsigned)G);
         if (io_dtype == KVQ_F32) hipLaunchKernelGGL(vq_bwd_gz_kernel<KVQ_F32>, grid, dim3(256), 0, st, p);
@@ -650,10 +905,9 @@ int kvq_vq_backward(const void* z, const float* E, const int64_t* idx, const voi
         if (rc) return rc;
     }
     if (g_E) {
-        const int threads = D >= 256 ? 256 : (D + 63) / 64 * 64;
         dim3 grid((unsigned)K, (unsigned)p.T, (unsigned)G);
-        if (io_dtype == KVQ_F32) hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_F32, 0>), grid, dim3(threads), 0, st, p);
-        else hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_BF16, 0>), grid, dim3(threads), 0, st, p);
+        if (io_dtype == KVQ_F32) hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_F32, 0>), grid, dim3(SEG_THREADS), 0, st, p);
+        else hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_BF16, 0>), grid, dim3(SEG_THREADS), 0, st, p);
         int rc = check_launch("vq_seg_sum_kernel");
         if (rc) return rc;
         const size_t KD = (size_t)K * D;
@@ -678,16 +932,16 @@ int kvq_vq_ema_update(const void* z, const int64_t* idx, int64_t N, int K, int D
     BwdParams p;
     p.z = z; p.E = nullptr; p.idx = idx; p.g_zq = nullptr; p.g_loss = nullptr; p.g_z = nullptr; p.g_E = nullptr;
     p.slab = (float*)(w + l.slab);
-    p.N = N; p.K = K; p.D = D; p.T = pick_T(N, K); p.chunk = chunk_of(N, p.T); p.beta = 0.f;
+    p.N = N; p.K = K; p.D = D; p.T = pick_T(N, K, D); p.chunk = chunk_of(N, p.T); p.beta = 0.f;
+    p.slab_cnt = (int*)(w + l.slab_cnt);
     (void)hipMemsetAsync(cnt, 0, (size_t)G * K * sizeof(unsigned), st);
     hipLaunchKernelGGL(vq_ema_counts_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)G), dim3(256), 0, st, idx, N, K, cnt);
     hipLaunchKernelGGL(vq_ema_n_kernel, dim3((unsigned)G), dim3(256), 0, st, cnt, K, decay, ema_n, tot);
-    const int threads = D >= 256 ? 256 : (D + 63) / 64 * 64;
     dim3 grid((unsigned)K, (unsigned)p.T, (unsigned)G);
-    if (io_dtype == KVQ_F32) hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_F32, 1>), grid, dim3(threads), 0, st, p);
-    else hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_BF16, 1>), grid, dim3(threads), 0, st, p);
+    if (io_dtype == KVQ_F32) hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_F32, 1>), grid, dim3(SEG_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_BF16, 1>), grid, dim3(SEG_THREADS), 0, st, p);
     const size_t KD = (size_t)K * D;
-    hipLaunchKernelGGL(vq_ema_apply_kernel, dim3((unsigned)((KD + 255) / 256), (unsigned)G), dim3(256), 0, st, p.slab, p.T, K, D,
+    hipLaunchKernelGGL(vq_ema_apply_kernel, dim3((unsigned)((KD + 255) / 256), (unsigned)G), dim3(256), 0, st, p.slab, p.slab_cnt, p.T, K, D,
                        decay, eps, ema_n, tot, ema_m, E);
     return check_launch("vq_ema_update");
 }

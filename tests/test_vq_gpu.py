@@ -83,9 +83,28 @@ def test_backward_vs_oracle_and_reference(kvq, name):
     assert not got["grad_E"][unused].any()
 
 
+@pytest.fixture(params=[2, 1], ids=["tiled", "fused"])
+def variant(request, kvq):
+    """Both MFMA forward structures (include/kvq.h kvq_vq_set_forward_variant) must give identical bits."""
+    lib = kvq._ffi.lib()
+    assert lib.kvq_vq_set_forward_variant(request.param) == 0
+    yield request.param
+    lib.kvq_vq_set_forward_variant(2)
+
+
+@pytest.mark.parametrize("name", ["c1_sep", "c1_default", "k8192_sep", "demo_default"])
+def test_forward_both_variants_vs_oracle(kvq, variant, name):
+    c = load_case(name)
+    got = _run(kvq, c["z"], c["E"], float(c["beta"]))
+    ora = O.vq_forward(c["z"], c["E"], float(c["beta"]))
+    assert np.array_equal(got["idx"], ora["idx"]) and np.array_equal(got["z_q"], ora["z_q"].reshape(-1, c["D"]))
+    assert np.array_equal(got["counts"], ora["counts"])
+    np.testing.assert_allclose(got["loss"], ora["loss"], rtol=1e-6)
+
+
 @pytest.mark.parametrize("shape", [(64, 512, 768), (100, 300, 128), (33, 37, 64), (256, 8192, 64)])
 @pytest.mark.parametrize("regime", ["sep", "near_tie"])
-def test_mfma_distances_bitwise_equal_oracle(kvq, shape, regime):
+def test_mfma_distances_bitwise_equal_oracle(kvq, variant, shape, regime):
     """The f32 MFMA contraction must be the documented fmaf chain: distance matrices equal bit for bit."""
     N, K, D = shape
     rng = np.random.default_rng(N + K + D)
@@ -238,3 +257,25 @@ def test_ema_update_matches_textbook_oracle(kvq):
     np.testing.assert_allclose(tn.cpu().numpy(), n2, rtol=1e-6)
     np.testing.assert_allclose(tm.cpu().numpy(), m2, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(tE.cpu().numpy(), E2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,K,D", [(8192, 512, 768), (5000, 10, 768), (700, 37, 40)])
+def test_collapsed_codebook(kvq, N, K, D):
+    """Codebook collapse (every token on one or two codes) is the common failure mode of VQ training and the
+    worst case for histogram / scatter contention: results must not change, only (at most) speed."""
+    rng = np.random.default_rng(N + K)
+    E = rng.standard_normal((K, D), dtype=np.float32)
+    hot = np.where(rng.random(N) < 0.97, 3, K - 1)
+    z = (E[hot] + 0.05 * rng.standard_normal((N, D), dtype=np.float32)).astype(np.float32)
+    g = rng.standard_normal((N, D), dtype=np.float32)
+    got = _run(kvq, z, E, 0.25, g, 1.3)
+    assert np.array_equal(got["idx"], hot)
+    assert got["counts"][3] == (hot == 3).sum() and got["counts"].sum() == N
+    O.set_threads(8)
+    ora = O.vq_forward(z, E, 0.25)
+    O.set_threads(1)
+    assert np.array_equal(got["idx"], ora["idx"]) and np.array_equal(got["z_q"], ora["z_q"])
+    np.testing.assert_allclose(got["loss"], ora["loss"], rtol=1e-6)
+    gz, gE = O.vq_backward(z, E, got["idx"], g, 1.3, 0.25)
+    np.testing.assert_allclose(got["grad_z"], gz, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(got["grad_E"], gE, rtol=1e-4, atol=1e-9)
