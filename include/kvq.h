@@ -133,12 +133,58 @@ int kvq_vq_ema_update(const void* z, const int64_t* idx, int64_t N, int K, int D
  *   loss [1] f32 = mean(row_loss) ; acc [1] f32 = mean(pred == target)  (common/metrics.py:18-30)
  * The [N,V] one-hot of the reference (1 GB at N=8192) is never built.
  */
-int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, int io_dtype,
+int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, int64_t ld, int io_dtype,
                    float* row_loss, float* row_lse, int64_t* pred, float* loss, float* acc, void* stream);
 
 /* g_logits[n,v] = g_loss/N * (softmax(logits_n)[v] - [v == target_n]); may alias logits (in place). */
 int kvq_ce_backward(const void* logits, const int64_t* target, const float* row_lse, const float* g_loss,
-                    int64_t N, int V, int io_dtype, void* g_logits, void* stream);
+                    int64_t N, int V, int64_t ld, int io_dtype, void* g_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Memory-bound pieces of the BERT blocks (HuggingFace modeling_bert.py as used by models/bagon/Bagon.py:24-31),
+ * one kernel pass per block boundary; bf16 or f32 activations, f32 arithmetic.  `seed`/`site` key the counter-based
+ * dropout generator (Philox4x32-10): forward and backward regenerate the same mask, nothing is stored.
+ */
+
+/* BertSelfOutput / BertOutput (:282-293, :340-352):  out = LayerNorm(dropout(y) + resid).
+ *   y, resid (may be NULL), out, pre [N,H] io dtype; gamma, beta [H] f32; pre (may be NULL) = dropout(y)+resid as stored;
+ *   mean, rstd [N] f32 (may be NULL).  H %% 4 == 0, H <= 4096. */
+int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
+                                float eps, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* pre,
+                                float* mean, float* rstd, void* stream);
+size_t kvq_ln_bwd_workspace_bytes(int64_t N, int H);
+/* g_y = d/dy, g_resid = d/dresid (either may be NULL); g_gamma, g_beta [H] in param_grad_dtype, overwritten or
+ * accumulated into (accumulate != 0); either may be NULL. */
+int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float* mean, const float* rstd, const float* gamma,
+                                int64_t N, int H, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* g_y,
+                                void* g_resid, void* g_gamma, void* g_beta, int param_grad_dtype, int accumulate, void* ws,
+                                size_t ws_bytes, void* stream);
+
+/* out[c] (= or +=) scale * sum_n x[n,c]   (bias gradients).  x [N, ld] in_dtype, out [C] out_dtype. */
+size_t kvq_colsum_workspace_bytes(int64_t N, int64_t C);
+int kvq_colsum(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, void* out, int out_dtype, float scale,
+               int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* BertIntermediate activation (:325-337), erf GELU.  n elements, n %% 4 == 0. */
+int kvq_gelu_fwd(const void* h, void* a, int64_t n, int io_dtype, void* stream);
+int kvq_gelu_bwd(const void* h, const void* g_a, void* g_h, int64_t n, int io_dtype, void* stream);
+
+/* BertSelfAttention / BertCrossAttention core (:111-204) for S_q, S_k <= 32 and head dim 64: softmax(q k^T * scale + mask) v
+ * with dropout on the probabilities.  q [B*Sq, ldq], k/v [B*Sk, ldk/ldv], out [B*Sq, ldo]; head h lives at columns h*64..;
+ * mask [B,Sk] int64 (1 = attend) or NULL; causal != 0 adds key <= query.  lse [B,nh,Sq] (may be NULL). */
+int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mask, int B, int nh, int Sq, int Sk, int dh,
+                 int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed, uint32_t site,
+                 int io_dtype, void* out, float* lse, void* stream);
+int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mask, const void* g_out, int B, int nh, int Sq,
+                 int Sk, int dh, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed,
+                 uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v, void* stream);
+
+/* torch.optim.Adam step (models/shelgon3/main.py:91: lr, weight_decay (L2, coupled), amsgrad) on flat buffers.
+ *   p, m, v [, vmax] f32; g grad_dtype (scaled by grad_scale first); shadow_bf16 (may be NULL) receives bf16(p_new).
+ *   step >= 1 is the 1-based step count for bias correction.  n %% 4 == 0. */
+int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                  void* stream);
 
 #ifdef __cplusplus
 }

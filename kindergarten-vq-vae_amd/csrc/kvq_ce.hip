@@ -21,8 +21,8 @@ struct RowWalk {
     static constexpr int VEC = 16 / IO<DT>::bytes;
     const char* base;  // row start
     int V, head, nvec, tail0;
-    __device__ RowWalk(const void* p, int64_t n, int V_) : V(V_) {
-        base = reinterpret_cast<const char*>(p) + (size_t)n * V_ * IO<DT>::bytes;
+    __device__ RowWalk(const void* p, int64_t n, int V_, int64_t ld) : V(V_) {
+        base = reinterpret_cast<const char*>(p) + (size_t)n * ld * IO<DT>::bytes;
         const int mis = (int)((uintptr_t)base & 15);
         head = mis ? (16 - mis) / IO<DT>::bytes : 0;
         head = head < V ? head : V;
@@ -68,13 +68,13 @@ __device__ __forceinline__ void ms_merge(MaxSum& a, float m, float s, float bv, 
 
 template <int DT>
 __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const void* __restrict__ logits, const int64_t* __restrict__ target,
-                                                             int64_t N, int V, float* __restrict__ row_loss,
+                                                             int64_t N, int V, int64_t ld, float* __restrict__ row_loss,
                                                              float* __restrict__ row_lse, int64_t* __restrict__ pred) {
     __shared__ float sm[CE_THREADS / WAVE], ss[CE_THREADS / WAVE], sv[CE_THREADS / WAVE];
     __shared__ int si[CE_THREADS / WAVE];
     const int64_t n = blockIdx.x;
     const int t = threadIdx.x;
-    RowWalk<DT> rw(logits, n, V);
+    RowWalk<DT> rw(logits, n, V, ld);
     constexpr int VEC = RowWalk<DT>::VEC;
     MaxSum a = {-INFINITY, 0.f, -INFINITY, INT_MAX};
     if (t < rw.head) ms_push(a, IO<DT>::load1(rw.base, t), t);
@@ -129,12 +129,13 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
 template <int DT>
 __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const void* logits, const int64_t* __restrict__ target,
                                                              const float* __restrict__ row_lse, const float* __restrict__ g_loss,
-                                                             int64_t N, int V, void* g_logits) {
+                                                             int64_t N, int V, int64_t ld, void* g_logits) {
     const int64_t n = blockIdx.x;
     const int t = threadIdx.x;
-    RowWalk<DT> rw(logits, n, V);
+    RowWalk<DT> rw(logits, n, V, ld);
     constexpr int VEC = RowWalk<DT>::VEC;
-    char* out = reinterpret_cast<char*>(g_logits) + (size_t)n * V * IO<DT>::bytes;
+    char* out = reinterpret_cast<char*>(g_logits) + (size_t)n * ld * IO<DT>::bytes;
+    for (int j = V + t; j < ld; j += CE_THREADS) IO<DT>::store1(out, j, 0.f);   // padding columns carry no gradient
     const float c = (g_loss ? *g_loss : 1.0f) / (float)N;
     const float lse = row_lse[n];
     const int tg = (int)target[n];
@@ -172,17 +173,17 @@ using namespace kvq;
 
 extern "C" {
 
-int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, int io_dtype, float* row_loss,
+int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, int64_t ld, int io_dtype, float* row_loss,
                    float* row_lse, int64_t* pred, float* loss, float* acc, void* stream) {
     KVQ_REQUIRE(logits && target && row_loss && row_lse && pred, "kvq_ce_forward: null pointer argument");
-    KVQ_REQUIRE(N > 0 && V > 0 && N < (1ll << 31), "kvq_ce_forward: N=%lld V=%d out of range", (long long)N, V);
+    KVQ_REQUIRE(N > 0 && V > 0 && N < (1ll << 31) && ld >= V, "kvq_ce_forward: N=%lld V=%d ld=%lld out of range", (long long)N, V, (long long)ld);
     KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "kvq_ce_forward: unsupported io dtype %d", io_dtype);
     KVQ_REQUIRE(((uintptr_t)logits & (io_dtype == KVQ_F32 ? 3 : 1)) == 0, "kvq_ce_forward: misaligned logits");
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == KVQ_F32)
-        hipLaunchKernelGGL(ce_fwd_kernel<KVQ_F32>, dim3((unsigned)N), dim3(CE_THREADS), 0, st, logits, target, N, V, row_loss, row_lse, pred);
+        hipLaunchKernelGGL(ce_fwd_kernel<KVQ_F32>, dim3((unsigned)N), dim3(CE_THREADS), 0, st, logits, target, N, V, ld, row_loss, row_lse, pred);
     else
-        hipLaunchKernelGGL(ce_fwd_kernel<KVQ_BF16>, dim3((unsigned)N), dim3(CE_THREADS), 0, st, logits, target, N, V, row_loss, row_lse, pred);
+        hipLaunchKernelGGL(ce_fwd_kernel<KVQ_BF16>, dim3((unsigned)N), dim3(CE_THREADS), 0, st, logits, target, N, V, ld, row_loss, row_lse, pred);
     int rc = check_launch("ce_fwd_kernel");
     if (rc) return rc;
     if (loss || acc) {
@@ -193,15 +194,15 @@ int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, 
 }
 
 int kvq_ce_backward(const void* logits, const int64_t* target, const float* row_lse, const float* g_loss, int64_t N,
-                    int V, int io_dtype, void* g_logits, void* stream) {
+                    int V, int64_t ld, int io_dtype, void* g_logits, void* stream) {
     KVQ_REQUIRE(logits && target && row_lse && g_logits, "kvq_ce_backward: null pointer argument");
-    KVQ_REQUIRE(N > 0 && V > 0 && N < (1ll << 31), "kvq_ce_backward: N=%lld V=%d out of range", (long long)N, V);
+    KVQ_REQUIRE(N > 0 && V > 0 && N < (1ll << 31) && ld >= V, "kvq_ce_backward: N=%lld V=%d ld=%lld out of range", (long long)N, V, (long long)ld);
     KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "kvq_ce_backward: unsupported io dtype %d", io_dtype);
     hipStream_t st = (hipStream_t)stream;
     if (io_dtype == KVQ_F32)
-        hipLaunchKernelGGL(ce_bwd_kernel<KVQ_F32>, dim3((unsigned)N), dim3(CE_THREADS), 0, st, logits, target, row_lse, g_loss, N, V, g_logits);
+        hipLaunchKernelGGL(ce_bwd_kernel<KVQ_F32>, dim3((unsigned)N), dim3(CE_THREADS), 0, st, logits, target, row_lse, g_loss, N, V, ld, g_logits);
     else
-        hipLaunchKernelGGL(ce_bwd_kernel<KVQ_BF16>, dim3((unsigned)N), dim3(CE_THREADS), 0, st, logits, target, row_lse, g_loss, N, V, g_logits);
+        hipLaunchKernelGGL(ce_bwd_kernel<KVQ_BF16>, dim3((unsigned)N), dim3(CE_THREADS), 0, st, logits, target, row_lse, g_loss, N, V, ld, g_logits);
     return check_launch("ce_bwd_kernel");
 }
 

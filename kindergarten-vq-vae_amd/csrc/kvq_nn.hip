@@ -1,0 +1,693 @@
+// kvq_nn.hip -- the memory-bound pieces of the BERT encoder/decoder blocks of the training step, fused for gfx950.
+//
+// The reference runs these as separate ATen ops inside HuggingFace's BertLayer (modeling_bert.py:139-352): bias add,
+// dropout, residual add, LayerNorm, GELU, softmax attention, and torch.optim.Adam.  Here each block boundary is one
+// kernel pass over the activations (bf16 storage, f32 arithmetic):
+//   kvq_dropout_residual_ln_{fwd,bwd}   BertSelfOutput / BertOutput (:282-293, :340-352): LN(dropout(y) + residual)
+//   kvq_gelu_{fwd,bwd}                   BertIntermediate activation (:325-337), erf form
+//   kvq_colsum                           bias gradients (sum over tokens)
+//   kvq_attn_{fwd,bwd}                   BertSelfAttention / BertCrossAttention core (:111-204) for sentences of <= 32 tokens:
+//                                        one wave per (sentence, head), scores never leave registers / LDS
+//   kvq_adam_step                        torch.optim.Adam semantics (main.py:91) on flat buffers + bf16 shadow weights
+// Dropout masks are never stored: both directions regenerate them from a counter-based generator (Philox4x32-10)
+// keyed by (seed, site) and indexed by the element position.
+#include <math.h>
+
+#include "kvq_common.h"
+
+namespace kvq {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011).  One call -> 4 x 32 random bits for counter (c0..c3), key (k0,k1).
+// ---------------------------------------------------------------------------------------------------------------
+struct U4 {
+    unsigned x, y, z, w;
+};
+__device__ __forceinline__ U4 philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+// keep-mask for 4 consecutive elements starting at element index e4*4 of dropout site `site`
+__device__ __forceinline__ U4 drop_bits(unsigned long long seed, unsigned site, unsigned long long e4) {
+    return philox4x32((unsigned)e4, (unsigned)(e4 >> 32), site, 0x5eedu, (unsigned)seed, (unsigned)(seed >> 32));
+}
+__device__ __forceinline__ float keep_scale(unsigned bits, unsigned thresh, float inv_keep) {
+    return bits >= thresh ? inv_keep : 0.f;   // P(drop) = thresh / 2^32
+}
+static inline unsigned drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (unsigned)t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LN(dropout(y) + residual): one wave per row, rows of H <= 4096 (H % 4 == 0); bf16 or f32 io
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAX_PER_LANE = 16;   // H <= 64 * 4 * 16 = 4096
+
+template <int DT, int PER>
+__global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ y, const void* __restrict__ resid,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int64_t N, int H, float eps, float p_drop, unsigned thresh,
+                                                        unsigned long long seed, unsigned site, void* __restrict__ out,
+                                                        void* __restrict__ pre, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int nchunk = H >> 2;
+    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    f32x4 v[PER];
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int c = lane + WAVE * t;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (c < nchunk) {
+            const size_t off = (size_t)row * H + 4 * c;
+            a = IO<DT>::load4(y, off);
+            if (p_drop > 0.f) {
+                const U4 b = drop_bits(seed, site, (unsigned long long)row * nchunk + c);
+                a.x *= keep_scale(b.x, thresh, inv_keep); a.y *= keep_scale(b.y, thresh, inv_keep);
+                a.z *= keep_scale(b.z, thresh, inv_keep); a.w *= keep_scale(b.w, thresh, inv_keep);
+            }
+            if (resid) a += IO<DT>::load4(resid, off);
+            // LayerNorm sees the STORED pre-activation (bf16-rounded when io is bf16): backward re-reads exactly that
+            a.x = IO<DT>::round(a.x); a.y = IO<DT>::round(a.y); a.z = IO<DT>::round(a.z); a.w = IO<DT>::round(a.w);
+            if (pre) IO<DT>::store4(pre, off, a);
+            sum += (a.x + a.y) + (a.z + a.w);
+        }
+        v[t] = a;
+    }
+    const float mean = wave_sum_f32(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        if (lane + WAVE * t < nchunk) {
+            const f32x4 d = v[t] - mean;
+            sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+    }
+    const float var = wave_sum_f32(sq) / (float)H;
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int c = lane + WAVE * t;
+        if (c < nchunk) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c);
+            const f32x4 o = (v[t] - mean) * rstd * g + b;
+            IO<DT>::store4(out, (size_t)row * H + 4 * c, o);
+        }
+    }
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+// backward: g_pre = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  g_resid = g_pre;
+//           g_y = g_pre * dropout_mask/(1-p);  dgamma/dbeta partials per workgroup (summed by colsum_final_kernel)
+constexpr int LNB_ROWS = 32;   // rows per workgroup (4 waves x 8 rows)
+
+template <int DT, int PER>
+__global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ g_out, const void* __restrict__ pre,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, int64_t N, int H, float p_drop,
+                                                        unsigned thresh, unsigned long long seed, unsigned site,
+                                                        void* __restrict__ g_y, void* __restrict__ g_resid,
+                                                        float* __restrict__ part_dgamma, float* __restrict__ part_dbeta) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][2][H]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nchunk = H >> 2;
+    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    f32x4 dg[PER], db[PER], gm[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        dg[t] = 0.f; db[t] = 0.f;
+        const int c = lane + WAVE * t;
+        f32x4 one = {0.f, 0.f, 0.f, 0.f};
+        gm[t] = c < nchunk ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : one;
+    }
+    for (int r = 0; r < LNB_ROWS / 4; ++r) {
+        const int64_t row = (int64_t)blockIdx.x * LNB_ROWS + w * (LNB_ROWS / 4) + r;
+        if (row >= N) break;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 gg[PER], xh[PER];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int c = lane + WAVE * t;
+            f32x4 tt = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
+            if (c < nchunk) {
+                const size_t off = (size_t)row * H + 4 * c;
+                const f32x4 go = IO<DT>::load4(g_out, off);
+                x = (IO<DT>::load4(pre, off) - mu) * rs;
+                tt = go * gm[t];
+                dg[t] += go * x;
+                db[t] += go;
+                s1 += (tt.x + tt.y) + (tt.z + tt.w);
+                s2 += (tt.x * x.x + tt.y * x.y) + (tt.z * x.z + tt.w * x.w);
+            }
+            gg[t] = tt; xh[t] = x;
+        }
+        s1 = wave_sum_f32(s1) / (float)H;
+        s2 = wave_sum_f32(s2) / (float)H;
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int c = lane + WAVE * t;
+            if (c < nchunk) {
+                const size_t off = (size_t)row * H + 4 * c;
+                f32x4 gp = (gg[t] - s1 - xh[t] * s2) * rs;
+                if (g_resid) IO<DT>::store4(g_resid, off, gp);
+                if (g_y) {
+                    if (p_drop > 0.f) {
+                        const U4 b = drop_bits(seed, site, (unsigned long long)row * nchunk + c);
+                        gp.x *= keep_scale(b.x, thresh, inv_keep); gp.y *= keep_scale(b.y, thresh, inv_keep);
+                        gp.z *= keep_scale(b.z, thresh, inv_keep); gp.w *= keep_scale(b.w, thresh, inv_keep);
+                    }
+                    IO<DT>::store4(g_y, off, gp);
+                }
+            }
+        }
+    }
+    float* l_dg = lds + (size_t)w * 2 * H;
+    float* l_db = l_dg + H;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int c = lane + WAVE * t;
+        if (c < nchunk) {
+            *reinterpret_cast<f32x4*>(l_dg + 4 * c) = dg[t];
+            *reinterpret_cast<f32x4*>(l_db + 4 * c) = db[t];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < H; j += 256) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { a += lds[(size_t)ww * 2 * H + j]; b += lds[(size_t)ww * 2 * H + H + j]; }
+        part_dgamma[(size_t)blockIdx.x * H + j] = a;
+        part_dbeta[(size_t)blockIdx.x * H + j] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// column sums: out[c] = sum_n x[n,c]  (bias gradients; also the second stage of the LN partials).
+// Two kernels: row-block partials (coalesced, each thread owns 4 or 8 columns), then a fixed-order final sum.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CS_ROWS = 128;   // rows per partial block
+
+template <int DT_IN>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ x, int64_t N, int64_t C,
+                                                              int64_t ld, float* __restrict__ part) {
+    // grid (ceil(C/1024), ceil(N/CS_ROWS)); thread owns 4 consecutive columns
+    const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    const int64_t r1 = r0 + CS_ROWS < N ? r0 + CS_ROWS : N;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (c0 + 4 <= C) && (((size_t)ld * IO<DT_IN>::bytes) % (4 * IO<DT_IN>::bytes) == 0) &&
+                     ((((uintptr_t)x) + (size_t)c0 * IO<DT_IN>::bytes) % (4 * IO<DT_IN>::bytes) == 0);
+    if (vec) {
+        for (int64_t r = r0; r < r1; ++r) a += IO<DT_IN>::load4(x, (size_t)r * ld + c0);
+    } else {
+        for (int64_t r = r0; r < r1; ++r)
+            for (int u = 0; u < 4 && c0 + u < C; ++u) a[u] += IO<DT_IN>::load1(x, (size_t)r * ld + c0 + u);
+    }
+    for (int u = 0; u < 4 && c0 + u < C; ++u) part[(size_t)blockIdx.y * C + c0 + u] = a[u];
+}
+
+template <int DT_OUT>
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int64_t P, int64_t C,
+                                                            void* __restrict__ out, float scale, int accumulate) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int64_t p = 0; p < P; ++p) a += part[(size_t)p * C + c];
+    a *= scale;
+    if (accumulate) a += IO<DT_OUT>::load1(out, c);
+    IO<DT_OUT>::store1(out, c, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GELU (erf form), elementwise.  fwd: a = gelu(h);  bwd: g_h = g_a * gelu'(h)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+template <int DT, bool BWD>
+__global__ __launch_bounds__(256) void gelu_kernel(const void* __restrict__ h, const void* __restrict__ g_a,
+                                                    void* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 x = IO<DT>::load4(h, 4 * i);
+        f32x4 o;
+        if (BWD) {
+            const f32x4 g = IO<DT>::load4(g_a, 4 * i);
+            o.x = g.x * gelu_grad_f(x.x); o.y = g.y * gelu_grad_f(x.y);
+            o.z = g.z * gelu_grad_f(x.z); o.w = g.w * gelu_grad_f(x.w);
+        } else {
+            o.x = gelu_f(x.x); o.y = gelu_f(x.y); o.z = gelu_f(x.z); o.w = gelu_f(x.w);
+        }
+        IO<DT>::store4(out, 4 * i, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, coupled L2 weight decay, optional amsgrad) on flat buffers:
+//   p32 (master, f32), g (bf16 or f32), m, v (f32) [, vmax], shadow (bf16 copy of p32 for the next forward)
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT_G>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, float* __restrict__ vmax,
+                                                    unsigned short* __restrict__ shadow, int64_t n4, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pv = *reinterpret_cast<f32x4*>(p + 4 * i);
+        f32x4 gv = IO<DT_G>::load4(g, 4 * i) * grad_scale;
+        f32x4 mv = *reinterpret_cast<f32x4*>(m + 4 * i);
+        f32x4 vv = *reinterpret_cast<f32x4*>(v + 4 * i);
+        gv += pv * wd;
+        mv = mv * b1 + gv * (1.0f - b1);
+        vv = vv * b2 + (gv * gv) * (1.0f - b2);
+        f32x4 den_src = vv;
+        if (vmax) {
+            f32x4 vm = *reinterpret_cast<f32x4*>(vmax + 4 * i);
+            vm.x = fmaxf(vm.x, vv.x); vm.y = fmaxf(vm.y, vv.y); vm.z = fmaxf(vm.z, vv.z); vm.w = fmaxf(vm.w, vv.w);
+            *reinterpret_cast<f32x4*>(vmax + 4 * i) = vm;
+            den_src = vm;
+        }
+        f32x4 den;
+        den.x = sqrtf(den_src.x) / bc2_sqrt + eps; den.y = sqrtf(den_src.y) / bc2_sqrt + eps;
+        den.z = sqrtf(den_src.z) / bc2_sqrt + eps; den.w = sqrtf(den_src.w) / bc2_sqrt + eps;
+        const float step = lr / bc1;
+        pv.x -= step * (mv.x / den.x); pv.y -= step * (mv.y / den.y);
+        pv.z -= step * (mv.z / den.z); pv.w -= step * (mv.w / den.w);
+        *reinterpret_cast<f32x4*>(p + 4 * i) = pv;
+        *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
+        *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+        if (shadow) IO<KVQ_BF16>::store4(shadow, 4 * i, pv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention for short sentences: S_q, S_k <= 32, head dim 64.  One wave per (sentence, head).
+//   lane = (query i = lane & 31, half h = lane >> 5).  QK^T: the lane scores its query against keys 16h..16h+15
+//   (K rows are LDS broadcasts); softmax row = 16 in-lane values + one exchange with lane^32; PV: the lane produces
+//   output dims 32h..32h+31 of its query over all keys.  Backward recomputes P, then switches to lane = key for the
+//   two reductions over queries (dK, dV) through 8 KiB of LDS.  All arithmetic f32, io bf16 or f32.
+//   q: [B*Sq, ldq] rows, head hd at columns hd*64; k, v likewise with ldk; mask [B, Sk] (1 = keep) or NULL.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int AT_S = 32;
+constexpr int AT_D = 64;
+
+struct AttnParams {
+    const void *q, *k, *v;
+    void* out;            // fwd: ctx [B*Sq, ldo]
+    float* lse;           // [B, nh, Sq] log-sum-exp of the scaled, masked scores
+    const int64_t* mask;  // [B, Sk] or null
+    // backward
+    const void* g_out;
+    void *g_q, *g_k, *g_v;
+    int B, nh, Sq, Sk;
+    int ldq, ldk, ldv, ldo;   // row strides in elements
+    int causal;
+    float scale, p_drop;
+    unsigned thresh;
+    unsigned long long seed;
+    unsigned site;
+};
+
+constexpr int AT_QLD = AT_D + 4;   // padded row stride (floats) of tiles that lanes read row-per-lane
+constexpr int AT_PLD = AT_S + 1;   // padded row stride of the 32x32 probability tiles
+
+// lane (row i, half h) copies its 32 elements of one row of a [rows, ld] matrix (head slice) into an LDS tile row
+template <int DT>
+__device__ __forceinline__ void stage_row(const void* base, size_t row_off, bool valid, float* tile_row) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (valid) t = IO<DT>::load4(base, row_off + 4 * c);
+        *reinterpret_cast<f32x4*>(tile_row + 4 * c) = t;
+    }
+}
+
+// dropout keep-scales of prob elements (b, head, i, j = 16h .. 16h+15): element index ((bh*32 + i)*32 + j), 4 per Philox call
+__device__ __forceinline__ void attn_keep16(const AttnParams& p, int bh, int i, int h, float (&keep)[16]) {
+    const float inv_keep = 1.0f / (1.0f - p.p_drop);
+    const unsigned long long e4 = (((unsigned long long)bh * AT_S + i) * AT_S + 16 * h) >> 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const U4 r = drop_bits(p.seed, p.site, e4 + c);
+        keep[4 * c] = keep_scale(r.x, p.thresh, inv_keep); keep[4 * c + 1] = keep_scale(r.y, p.thresh, inv_keep);
+        keep[4 * c + 2] = keep_scale(r.z, p.thresh, inv_keep); keep[4 * c + 3] = keep_scale(r.w, p.thresh, inv_keep);
+    }
+}
+
+// acc[jj] += A[i][:] . B[16h + jj][:]   (A row-per-lane tile with stride AT_QLD, B broadcast tile with stride ldb)
+__device__ __forceinline__ void rows_dot16(const float* Arow, const float* B, int ldb, int h, float (&acc)[16]) {
+#pragma unroll 2
+    for (int d = 0; d < AT_D; d += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Arow + d);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(B + (16 * h + jj) * ldb + d);
+            acc[jj] = __builtin_fmaf(a.x, bb.x, acc[jj]); acc[jj] = __builtin_fmaf(a.y, bb.y, acc[jj]);
+            acc[jj] = __builtin_fmaf(a.z, bb.z, acc[jj]); acc[jj] = __builtin_fmaf(a.w, bb.w, acc[jj]);
+        }
+    }
+}
+
+// o[0..31] += sum_j coef[j] * B[j][32h .. 32h+31]   with coef[j] = C[j * cs] (per-lane LDS scalar)
+__device__ __forceinline__ void weighted_rows32(const float* C, int cs, const float* B, int ldb, int h, float (&o)[32]) {
+#pragma unroll 2
+    for (int j = 0; j < AT_S; ++j) {
+        const float cj = C[j * cs];
+        const float* br = B + j * ldb + 32 * h;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(br + d);
+            o[d] = __builtin_fmaf(cj, bb.x, o[d]); o[d + 1] = __builtin_fmaf(cj, bb.y, o[d + 1]);
+            o[d + 2] = __builtin_fmaf(cj, bb.z, o[d + 2]); o[d + 3] = __builtin_fmaf(cj, bb.w, o[d + 3]);
+        }
+    }
+}
+
+// scaled + masked scores -> probabilities (before dropout) of query i against keys 16h..16h+15, and the row's lse
+__device__ __forceinline__ void scores_to_probs(const AttnParams& p, int b, int i, int h, bool qvalid, float (&s)[16], float& lse_out) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = 16 * h + jj;
+        bool ok = j < p.Sk && qvalid;
+        if (ok && p.mask) ok = p.mask[(size_t)b * p.Sk + j] != 0;
+        if (ok && p.causal) ok = j <= i;
+        s[jj] = ok ? s[jj] * p.scale : -INFINITY;
+        mx = fmaxf(mx, s[jj]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+    const float mref = mx == -INFINITY ? 0.f : mx;   // fully masked row -> all probabilities 0
+    float sum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        s[jj] = __expf(s[jj] - mref);
+        sum += s[jj];
+    }
+    sum += __shfl_xor(sum, 32, WAVE);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) s[jj] *= inv;
+    lse_out = mref + __logf(fmaxf(sum, 1e-37f));
+}
+
+__device__ __forceinline__ void store32(void* base, size_t off, const float (&o)[32], int dt) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        f32x4 t = {o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]};
+        if (dt == KVQ_F32) IO<KVQ_F32>::store4(base, off + 4 * c, t);
+        else IO<KVQ_BF16>::store4(base, off + 4 * c, t);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Ks[AT_S * AT_D];
+    __shared__ __attribute__((aligned(16))) float Vs[AT_S * AT_D];
+    __shared__ __attribute__((aligned(16))) float Qs[AT_S * AT_QLD];
+    __shared__ float Ps[AT_S * AT_PLD];
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+    const bool kvalid = i < p.Sk, qvalid = i < p.Sq;
+    stage_row<DT>(p.k, ((size_t)b * p.Sk + i) * p.ldk + hd * AT_D + 32 * h, kvalid, Ks + i * AT_D + 32 * h);
+    stage_row<DT>(p.v, ((size_t)b * p.Sk + i) * p.ldv + hd * AT_D + 32 * h, kvalid, Vs + i * AT_D + 32 * h);
+    stage_row<DT>(p.q, ((size_t)b * p.Sq + i) * p.ldq + hd * AT_D + 32 * h, qvalid, Qs + i * AT_QLD + 32 * h);
+    __syncthreads();
+    float s[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) s[jj] = 0.f;
+    rows_dot16(Qs + i * AT_QLD, Ks, AT_D, h, s);
+    float lse;
+    scores_to_probs(p, b, i, h, qvalid, s, lse);
+    if (p.p_drop > 0.f) {
+        float keep[16];
+        attn_keep16(p, bh, i, h, keep);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) s[jj] *= keep[jj];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Ps[i * AT_PLD + 16 * h + jj] = s[jj];
+    __syncthreads();
+    float o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    weighted_rows32(Ps + i * AT_PLD, 1, Vs, AT_D, h, o);      // out[i][32h + d] = sum_j P[i][j] V[j][32h + d]
+    if (qvalid) {
+        store32(p.out, ((size_t)b * p.Sq + i) * p.ldo + hd * AT_D + 32 * h, o, DT);
+        if (h == 0 && p.lse) p.lse[((size_t)b * p.nh + hd) * p.Sq + i] = lse;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Ks[AT_S * AT_D];
+    __shared__ __attribute__((aligned(16))) float Vs[AT_S * AT_D];
+    __shared__ __attribute__((aligned(16))) float Qs[AT_S * AT_QLD];
+    __shared__ __attribute__((aligned(16))) float Gs[AT_S * AT_QLD];
+    __shared__ float Ps[AT_S * AT_PLD];     // dropped probabilities  P~[i][j]
+    __shared__ float Ds[AT_S * AT_PLD];     // dS[i][j] (already times scale)
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+    const bool kvalid = i < p.Sk, qvalid = i < p.Sq;
+    stage_row<DT>(p.k, ((size_t)b * p.Sk + i) * p.ldk + hd * AT_D + 32 * h, kvalid, Ks + i * AT_D + 32 * h);
+    stage_row<DT>(p.v, ((size_t)b * p.Sk + i) * p.ldv + hd * AT_D + 32 * h, kvalid, Vs + i * AT_D + 32 * h);
+    stage_row<DT>(p.q, ((size_t)b * p.Sq + i) * p.ldq + hd * AT_D + 32 * h, qvalid, Qs + i * AT_QLD + 32 * h);
+    stage_row<DT>(p.g_out, ((size_t)b * p.Sq + i) * p.ldo + hd * AT_D + 32 * h, qvalid, Gs + i * AT_QLD + 32 * h);
+    __syncthreads();
+    float s[16], dp[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) { s[jj] = 0.f; dp[jj] = 0.f; }
+    rows_dot16(Qs + i * AT_QLD, Ks, AT_D, h, s);
+    float lse;
+    scores_to_probs(p, b, i, h, qvalid, s, lse);
+    rows_dot16(Gs + i * AT_QLD, Vs, AT_D, h, dp);            // dP~[i][j] = dO[i] . V[j]
+    float keep[16];
+    if (p.p_drop > 0.f) attn_keep16(p, bh, i, h, keep);
+    else {
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) keep[jj] = 1.0f;
+    }
+    // dP = dP~ * keep;  delta_i = sum_j P[i][j] dP[i][j];  dS = P * (dP - delta) * scale
+    float delta = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        dp[jj] *= keep[jj];
+        delta += s[jj] * dp[jj];
+    }
+    delta += __shfl_xor(delta, 32, WAVE);
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        Ps[i * AT_PLD + 16 * h + jj] = s[jj] * keep[jj];
+        Ds[i * AT_PLD + 16 * h + jj] = s[jj] * (dp[jj] - delta) * p.scale;
+    }
+    __syncthreads();
+    {
+        float o[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = 0.f;
+        weighted_rows32(Ds + i * AT_PLD, 1, Ks, AT_D, h, o);   // dQ[i][32h+d] = sum_j dS[i][j] K[j][32h+d]
+        if (qvalid) store32(p.g_q, ((size_t)b * p.Sq + i) * p.ldq + hd * AT_D + 32 * h, o, DT);
+    }
+    {   // lane = key j (= i): dK[j] = sum_q dS[q][j] Q[q];  dV[j] = sum_q P~[q][j] dO[q]
+        float o[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = 0.f;
+        weighted_rows32(Ds + i, AT_PLD, Qs, AT_QLD, h, o);
+        if (kvalid) store32(p.g_k, ((size_t)b * p.Sk + i) * p.ldk + hd * AT_D + 32 * h, o, DT);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = 0.f;
+        weighted_rows32(Ps + i, AT_PLD, Gs, AT_QLD, h, o);
+        if (kvalid) store32(p.g_v, ((size_t)b * p.Sk + i) * p.ldv + hd * AT_D + 32 * h, o, DT);
+    }
+}
+
+}  // namespace kvq
+
+using namespace kvq;
+
+#define DISPATCH_DT(dt, CALL_F32, CALL_BF16) \
+    do {                                     \
+        if ((dt) == KVQ_F32) { CALL_F32; } else { CALL_BF16; } \
+    } while (0)
+
+extern "C" {
+
+int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
+                                float eps, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* pre,
+                                float* mean, float* rstd, void* stream) {
+    KVQ_REQUIRE(y && gamma && beta && out && N > 0 && H > 0, "kvq_dropout_residual_ln_fwd: bad argument");
+    KVQ_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAX_PER_LANE, "kvq_dropout_residual_ln_fwd: H=%d must be a multiple of 4 and <= 4096", H);
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
+    KVQ_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop out of range");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((N + 3) / 4));
+    const unsigned th = drop_threshold(p_drop);
+#define LAUNCH_LN_FWD(DTV, PERV)                                                                                          \
+    hipLaunchKernelGGL((drln_fwd_kernel<DTV, PERV>), grid, dim3(256), 0, st, y, resid, gamma, beta, N, H, eps, p_drop, th, \
+                       (unsigned long long)seed, site, out, pre, mean, rstd)
+    if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 4), LAUNCH_LN_FWD(KVQ_BF16, 4)); }
+    else { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 16), LAUNCH_LN_FWD(KVQ_BF16, 16)); }
+#undef LAUNCH_LN_FWD
+    return check_launch("drln_fwd_kernel");
+}
+
+size_t kvq_ln_bwd_workspace_bytes(int64_t N, int H) {
+    const int64_t blocks = (N + LNB_ROWS - 1) / LNB_ROWS;
+    return (size_t)blocks * H * 2 * sizeof(float);
+}
+
+static int colsum_f32_partials(const float* part, int64_t P, int64_t C, void* out, int out_dtype, float scale, int accumulate,
+                               hipStream_t st) {
+    dim3 grid((unsigned)((C + 255) / 256));
+    DISPATCH_DT(out_dtype, hipLaunchKernelGGL(colsum_final_kernel<KVQ_F32>, grid, dim3(256), 0, st, part, P, C, out, scale, accumulate),
+                hipLaunchKernelGGL(colsum_final_kernel<KVQ_BF16>, grid, dim3(256), 0, st, part, P, C, out, scale, accumulate));
+    return check_launch("colsum_final_kernel");
+}
+
+int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float* mean, const float* rstd, const float* gamma,
+                                int64_t N, int H, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* g_y,
+                                void* g_resid, void* g_gamma, void* g_beta, int param_grad_dtype, int accumulate, void* ws,
+                                size_t ws_bytes, void* stream) {
+    KVQ_REQUIRE(g_out && pre && mean && rstd && gamma && N > 0 && H > 0, "kvq_dropout_residual_ln_bwd: bad argument");
+    KVQ_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAX_PER_LANE, "kvq_dropout_residual_ln_bwd: H=%d unsupported", H);
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
+    const size_t need = kvq_ln_bwd_workspace_bytes(N, H);
+    if (!ws || ws_bytes < need) return fail(KVQ_E_WORKSPACE, "kvq_dropout_residual_ln_bwd: workspace %zu < %zu", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t blocks = (N + LNB_ROWS - 1) / LNB_ROWS;
+    float* pdg = (float*)ws;
+    float* pdb = pdg + (size_t)blocks * H;
+    const size_t lds = (size_t)4 * 2 * H * sizeof(float);
+    const unsigned th = drop_threshold(p_drop);
+#define LAUNCH_LN_BWD(DTV, PERV)                                                                                             \
+    hipLaunchKernelGGL((drln_bwd_kernel<DTV, PERV>), dim3((unsigned)blocks), dim3(256), lds, st, g_out, pre, mean, rstd, gamma, \
+                       N, H, p_drop, th, (unsigned long long)seed, site, g_y, g_resid, pdg, pdb)
+    if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 4), LAUNCH_LN_BWD(KVQ_BF16, 4)); }
+    else { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 16), LAUNCH_LN_BWD(KVQ_BF16, 16)); }
+#undef LAUNCH_LN_BWD
+    int rc = check_launch("drln_bwd_kernel");
+    if (rc) return rc;
+    if (g_gamma) { rc = colsum_f32_partials(pdg, blocks, H, g_gamma, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
+    if (g_beta) { rc = colsum_f32_partials(pdb, blocks, H, g_beta, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
+    return KVQ_OK;
+}
+
+size_t kvq_colsum_workspace_bytes(int64_t N, int64_t C) { return (size_t)((N + CS_ROWS - 1) / CS_ROWS) * C * sizeof(float); }
+
+int kvq_colsum(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, void* out, int out_dtype, float scale,
+               int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    KVQ_REQUIRE(x && out && N > 0 && C > 0 && ld >= C, "kvq_colsum: bad argument");
+    const size_t need = kvq_colsum_workspace_bytes(N, C);
+    if (!ws || ws_bytes < need) return fail(KVQ_E_WORKSPACE, "kvq_colsum: workspace %zu < %zu", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t P = (N + CS_ROWS - 1) / CS_ROWS;
+    dim3 grid((unsigned)((C + 1023) / 1024), (unsigned)P);
+    DISPATCH_DT(in_dtype, hipLaunchKernelGGL(colsum_partial_kernel<KVQ_F32>, grid, dim3(256), 0, st, x, N, C, ld, (float*)ws),
+                hipLaunchKernelGGL(colsum_partial_kernel<KVQ_BF16>, grid, dim3(256), 0, st, x, N, C, ld, (float*)ws));
+    int rc = check_launch("colsum_partial_kernel");
+    if (rc) return rc;
+    return colsum_f32_partials((const float*)ws, P, C, out, out_dtype, scale, accumulate, st);
+}
+
+int kvq_gelu_fwd(const void* h, void* a, int64_t n, int io_dtype, void* stream) {
+    KVQ_REQUIRE(h && a && n > 0 && n % 4 == 0, "kvq_gelu_fwd: bad argument (n %% 4 == 0 required)");
+    const int64_t n4 = n / 4;
+    unsigned blocks = (unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(io_dtype, hipLaunchKernelGGL((gelu_kernel<KVQ_F32, false>), dim3(blocks), dim3(256), 0, st, h, nullptr, a, n4),
+                hipLaunchKernelGGL((gelu_kernel<KVQ_BF16, false>), dim3(blocks), dim3(256), 0, st, h, nullptr, a, n4));
+    return check_launch("gelu_kernel");
+}
+
+int kvq_gelu_bwd(const void* h, const void* g_a, void* g_h, int64_t n, int io_dtype, void* stream) {
+    KVQ_REQUIRE(h && g_a && g_h && n > 0 && n % 4 == 0, "kvq_gelu_bwd: bad argument (n %% 4 == 0 required)");
+    const int64_t n4 = n / 4;
+    unsigned blocks = (unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(io_dtype, hipLaunchKernelGGL((gelu_kernel<KVQ_F32, true>), dim3(blocks), dim3(256), 0, st, h, g_a, g_h, n4),
+                hipLaunchKernelGGL((gelu_kernel<KVQ_BF16, true>), dim3(blocks), dim3(256), 0, st, h, g_a, g_h, n4));
+    return check_launch("gelu_kernel");
+}
+
+int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                  void* stream) {
+    KVQ_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "kvq_adam_step: bad argument (n %% 4 == 0, step >= 1)");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    const int64_t n4 = n / 4;
+    unsigned blocks = (unsigned)((n4 + 255) / 256 > 32768 ? 32768 : (n4 + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(grad_dtype,
+                hipLaunchKernelGGL(adam_kernel<KVQ_F32>, dim3(blocks), dim3(256), 0, st, p, g, m, v, vmax, (unsigned short*)shadow_bf16, n4,
+                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale),
+                hipLaunchKernelGGL(adam_kernel<KVQ_BF16>, dim3(blocks), dim3(256), 0, st, p, g, m, v, vmax, (unsigned short*)shadow_bf16, n4,
+                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale));
+    return check_launch("adam_kernel");
+}
+
+static int attn_check(int B, int nh, int Sq, int Sk, int dh, int io_dtype) {
+    KVQ_REQUIRE(B > 0 && nh > 0 && Sq > 0 && Sk > 0, "kvq_attn: sizes must be positive");
+    KVQ_REQUIRE(Sq <= AT_S && Sk <= AT_S, "kvq_attn: sequence lengths (%d, %d) above the %d-token kernel limit", Sq, Sk, AT_S);
+    KVQ_REQUIRE(dh == AT_D, "kvq_attn: head dim %d unsupported (64 only)", dh);
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
+    return KVQ_OK;
+}
+
+int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mask, int B, int nh, int Sq, int Sk, int dh,
+                 int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed, uint32_t site,
+                 int io_dtype, void* out, float* lse, void* stream) {
+    KVQ_REQUIRE(q && k && v && out, "kvq_attn_fwd: null pointer argument");
+    int rc = attn_check(B, nh, Sq, Sk, dh, io_dtype);
+    if (rc) return rc;
+    AttnParams p = {};
+    p.q = q; p.k = k; p.v = v; p.out = out; p.lse = lse; p.mask = mask;
+    p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.causal = causal;
+    p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.site = site;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(attn_fwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p),
+                hipLaunchKernelGGL(attn_fwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p));
+    return check_launch("attn_fwd_kernel");
+}
+
+int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mask, const void* g_out, int B, int nh, int Sq,
+                 int Sk, int dh, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed,
+                 uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v, void* stream) {
+    KVQ_REQUIRE(q && k && v && g_out && g_q && g_k && g_v, "kvq_attn_bwd: null pointer argument");
+    int rc = attn_check(B, nh, Sq, Sk, dh, io_dtype);
+    if (rc) return rc;
+    AttnParams p = {};
+    p.q = q; p.k = k; p.v = v; p.mask = mask; p.g_out = g_out; p.g_q = g_q; p.g_k = g_k; p.g_v = g_v;
+    p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.causal = causal;
+    p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.site = site;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(attn_bwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p),
+                hipLaunchKernelGGL(attn_bwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p));
+    return check_launch("attn_bwd_kernel");
+}
+
+}  // extern "C"

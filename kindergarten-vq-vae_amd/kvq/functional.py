@@ -157,7 +157,7 @@ class _FusedCE(torch.autograd.Function):
         row_lse = torch.empty(N, dtype=torch.float32, device=dev)
         pred = torch.empty(N, dtype=torch.int64, device=dev)
         out = torch.empty(2, dtype=torch.float32, device=dev)
-        check(lib().kvq_ce_forward(logits.data_ptr(), target.data_ptr(), N, V, io_dtype_of(logits), row_loss.data_ptr(),
+        check(lib().kvq_ce_forward(logits.data_ptr(), target.data_ptr(), N, V, V, io_dtype_of(logits), row_loss.data_ptr(),
                                    row_lse.data_ptr(), pred.data_ptr(), out[0:].data_ptr(), out[1:].data_ptr(),
                                    stream_ptr()), "kvq_ce_forward")
         ctx.save_for_backward(logits, target, row_lse)
@@ -172,7 +172,7 @@ class _FusedCE(torch.autograd.Function):
         N, V = logits.shape
         g = logits if ctx.inplace else torch.empty_like(logits)
         g_loss = g_loss.contiguous().float()
-        check(lib().kvq_ce_backward(logits.data_ptr(), target.data_ptr(), row_lse.data_ptr(), g_loss.data_ptr(), N, V,
+        check(lib().kvq_ce_backward(logits.data_ptr(), target.data_ptr(), row_lse.data_ptr(), g_loss.data_ptr(), N, V, V,
                                     io_dtype_of(logits), g.data_ptr(), stream_ptr()), "kvq_ce_backward")
         return g, None, None
 

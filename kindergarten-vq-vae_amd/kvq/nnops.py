@@ -1,0 +1,92 @@
+"""Tensor-level wrappers of the fused block kernels in libkvq.so (csrc/kvq_nn.hip).  Plain functions, no autograd:
+the training engine (kvq/engine.py) calls forward and backward kernels explicitly.  All work goes to the current stream."""
+from __future__ import annotations
+
+import torch
+
+from ._ffi import check, io_dtype_of, lib, require_gpu, stream_ptr
+from .functional import _workspace
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def ln_fwd(y, resid, gamma, beta, eps, p_drop=0.0, seed=0, site=0, save_pre=True):
+    """out = LayerNorm(dropout(y) + resid).  Returns (out, pre, mean, rstd); pre = the LN input as stored."""
+    require_gpu(y, gamma, beta)
+    N, H = y.shape
+    out = torch.empty_like(y)
+    pre = torch.empty_like(y) if save_pre else None
+    mean = torch.empty(N, dtype=torch.float32, device=y.device)
+    rstd = torch.empty(N, dtype=torch.float32, device=y.device)
+    check(lib().kvq_dropout_residual_ln_fwd(y.data_ptr(), _p(resid), gamma.data_ptr(), beta.data_ptr(), N, H, float(eps),
+                                            float(p_drop), int(seed), int(site), io_dtype_of(y), out.data_ptr(), _p(pre),
+                                            mean.data_ptr(), rstd.data_ptr(), stream_ptr()), "kvq_dropout_residual_ln_fwd")
+    return out, pre, mean, rstd
+
+
+def ln_bwd(g_out, pre, mean, rstd, gamma, p_drop=0.0, seed=0, site=0, g_gamma=None, g_beta=None, accumulate=False,
+           need_g_y=True, need_g_resid=True):
+    """Returns (g_y, g_resid).  g_gamma / g_beta (f32 or bf16 [H]) are written (or accumulated into) when given."""
+    N, H = g_out.shape
+    g_y = torch.empty_like(g_out) if need_g_y else None
+    g_resid = torch.empty_like(g_out) if need_g_resid else None
+    l = lib()
+    ws = _workspace(g_out.device, l.kvq_ln_bwd_workspace_bytes(N, H))
+    pdt = io_dtype_of(g_gamma) if g_gamma is not None else (io_dtype_of(g_beta) if g_beta is not None else 0)
+    check(l.kvq_dropout_residual_ln_bwd(g_out.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), N, H,
+                                        float(p_drop), int(seed), int(site), io_dtype_of(g_out), _p(g_y), _p(g_resid), _p(g_gamma),
+                                        _p(g_beta), pdt, int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()),
+          "kvq_dropout_residual_ln_bwd")
+    return g_y, g_resid
+
+
+def colsum(x, out, scale=1.0, accumulate=False, cols=None):
+    """out[c] (= | +=) scale * sum_n x[n, c] for the first `cols` columns of a row-major 2-D tensor (row stride = x.stride(0))."""
+    N = x.shape[0]
+    C = x.shape[1] if cols is None else cols
+    l = lib()
+    ws = _workspace(x.device, l.kvq_colsum_workspace_bytes(N, C))
+    check(l.kvq_colsum(x.data_ptr(), N, C, x.stride(0), io_dtype_of(x), out.data_ptr(), io_dtype_of(out), float(scale),
+                       int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_colsum")
+    return out
+
+
+def gelu_fwd(h):
+    a = torch.empty_like(h)
+    check(lib().kvq_gelu_fwd(h.data_ptr(), a.data_ptr(), h.numel(), io_dtype_of(h), stream_ptr()), "kvq_gelu_fwd")
+    return a
+
+
+def gelu_bwd(h, g_a, out=None):
+    g_h = torch.empty_like(h) if out is None else out
+    check(lib().kvq_gelu_bwd(h.data_ptr(), g_a.data_ptr(), g_h.data_ptr(), h.numel(), io_dtype_of(h), stream_ptr()), "kvq_gelu_bwd")
+    return g_h
+
+
+def attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_drop=0.0, seed=0, site=0, out=None):
+    """q [B*Sq, >=nh*64] (any row stride), k, v [B*Sk, ...]; returns (ctx [B*Sq, nh*64], lse [B, nh, Sq])."""
+    require_gpu(q, k, v)
+    dh = 64
+    ctx = torch.empty((B * Sq, nh * dh), dtype=q.dtype, device=q.device) if out is None else out
+    lse = torch.empty((B, nh, Sq), dtype=torch.float32, device=q.device)
+    check(lib().kvq_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(mask), B, nh, Sq, Sk, dh, q.stride(0), k.stride(0),
+                             v.stride(0), ctx.stride(0), int(causal), 1.0 / 8.0, float(p_drop), int(seed), int(site),
+                             io_dtype_of(q), ctx.data_ptr(), lse.data_ptr(), stream_ptr()), "kvq_attn_fwd")
+    return ctx, lse
+
+
+def attn_bwd(q, k, v, mask, g_ctx, B, nh, Sq, Sk, causal, p_drop, seed, site, g_q, g_k, g_v):
+    """Writes g_q / g_k / g_v (same layouts / row strides as q / k / v)."""
+    dh = 64
+    assert g_q.stride(0) == q.stride(0) and g_k.stride(0) == k.stride(0) and g_v.stride(0) == v.stride(0)
+    check(lib().kvq_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(mask), g_ctx.data_ptr(), B, nh, Sq, Sk, dh, q.stride(0),
+                             k.stride(0), v.stride(0), g_ctx.stride(0), int(causal), 1.0 / 8.0, float(p_drop), int(seed), int(site),
+                             io_dtype_of(q), g_q.data_ptr(), g_k.data_ptr(), g_v.data_ptr(), stream_ptr()), "kvq_attn_bwd")
+
+
+def adam_step(p32, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, vmax=None, shadow=None, grad_scale=1.0):
+    check(lib().kvq_adam_step(p32.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(vmax), _p(shadow), p32.numel(),
+                              io_dtype_of(g), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                              float(grad_scale), stream_ptr()), "kvq_adam_step")

@@ -1,0 +1,206 @@
+"""GPU numerics of the fused block kernels (csrc/kvq_nn.hip) against plain PyTorch f32 references of the same ops
+(the ops HuggingFace's BertLayer runs: modeling_bert.py:111-352) and torch.optim.Adam."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from kvq import _ffi, nnops
+    _ffi.lib()
+    assert torch.cuda.is_available()
+    return nnops
+
+
+def _tol(dtype):
+    return dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("N,H", [(37, 768), (8, 64), (130, 3072), (5, 4096)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ln_fwd_bwd_no_dropout(ops, N, H, dtype):
+    torch.manual_seed(N + H)
+    y = torch.randn(N, H, device="cuda").to(dtype)
+    r = torch.randn(N, H, device="cuda").to(dtype)
+    gamma = torch.randn(H, device="cuda"); beta = torch.randn(H, device="cuda")
+    g = torch.randn(N, H, device="cuda").to(dtype)
+    out, pre, mean, rstd = ops.ln_fwd(y, r, gamma, beta, 1e-12)
+    yr = y.float().requires_grad_(True); rr = r.float().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    pre_ref = (yr + rr).to(dtype).float() if dtype != torch.float32 else yr + rr
+    ref = F.layer_norm((yr + rr), (H,), gr, br, 1e-12)
+    torch.testing.assert_close(out.float(), F.layer_norm(pre.float(), (H,), gamma, beta, 1e-12), **_tol(dtype))
+    torch.testing.assert_close(pre.float(), pre_ref.detach(), **_tol(dtype))
+    ref.backward(g.float())
+    gg = torch.zeros(H, device="cuda"); gb = torch.zeros(H, device="cuda")
+    g_y, g_r = ops.ln_bwd(g, pre, mean, rstd, gamma, g_gamma=gg, g_beta=gb)
+    t = _tol(dtype)
+    torch.testing.assert_close(g_y.float(), yr.grad, **t)
+    torch.testing.assert_close(g_r.float(), rr.grad, **t)
+    scale = math.sqrt(N)
+    torch.testing.assert_close(gg, gr.grad, rtol=t["rtol"], atol=t["atol"] * scale)
+    torch.testing.assert_close(gb, br.grad, rtol=t["rtol"], atol=t["atol"] * scale)
+    gg2 = torch.ones(H, device="cuda", dtype=torch.bfloat16)
+    ops.ln_bwd(g, pre, mean, rstd, gamma, g_gamma=gg2, accumulate=True, need_g_y=False, need_g_resid=False)
+    torch.testing.assert_close(gg2.float(), gr.grad + 1, rtol=2e-2, atol=2e-2 * scale)
+
+
+def test_ln_dropout_mask_consistency(ops):
+    """The mask is regenerated, not stored: forward and backward must see the same one, at the requested rate."""
+    N, H, p = 512, 768, 0.1
+    ones = torch.ones(N, H, device="cuda")
+    gamma = torch.randn(H, device="cuda"); beta = torch.zeros(H, device="cuda")
+    _, pre, mean, rstd = ops.ln_fwd(ones, None, gamma, beta, 1e-12, p, seed=123, site=7)
+    mask = pre > 0
+    assert torch.all((pre == 0) | torch.isclose(pre, torch.full_like(pre, 1 / (1 - p))))
+    rate = 1 - mask.float().mean().item()
+    assert abs(rate - p) < 0.005
+    _, pre2, _, _ = ops.ln_fwd(ones, None, gamma, beta, 1e-12, p, seed=123, site=8)
+    assert not torch.equal(pre, pre2)                       # another site -> another mask
+    _, pre3, _, _ = ops.ln_fwd(ones, None, gamma, beta, 1e-12, p, seed=123, site=7)
+    assert torch.equal(pre, pre3)                           # same (seed, site) -> same mask
+    y = torch.randn(N, H, device="cuda"); r = torch.randn(N, H, device="cuda"); g = torch.randn(N, H, device="cuda")
+    out, pre, mean, rstd = ops.ln_fwd(y, r, gamma, beta, 1e-12, p, seed=123, site=7)
+    yr = y.clone().requires_grad_(True); rr = r.clone().requires_grad_(True)
+    ref = F.layer_norm(yr * mask / (1 - p) + rr, (H,), gamma, beta, 1e-12)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    ref.backward(g)
+    g_y, g_r = ops.ln_bwd(g, pre, mean, rstd, gamma, p, 123, 7)
+    torch.testing.assert_close(g_y, yr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g_r, rr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,C,ld", [(8192, 768, 768), (300, 30522, 30528), (1000, 3072, 3072), (77, 13, 16), (5, 2304, 2304)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum(ops, N, C, ld, dtype):
+    torch.manual_seed(C)
+    buf = torch.randn(N, ld, device="cuda").to(dtype)
+    x = buf[:, :C]
+    out = torch.empty(C, device="cuda")
+    ops.colsum(buf, out, cols=C)
+    ref = x.float().sum(0)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-3)
+    out_b = torch.ones(C, device="cuda", dtype=torch.bfloat16)
+    ops.colsum(buf, out_b, scale=0.5, accumulate=True, cols=C)
+    torch.testing.assert_close(out_b.float(), 1 + 0.5 * ref, rtol=1e-2, atol=0.2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gelu(ops, dtype):
+    torch.manual_seed(0)
+    h = (3 * torch.randn(1000, 3072, device="cuda")).to(dtype)
+    g = torch.randn_like(h)
+    hr = h.float().requires_grad_(True)
+    ref = F.gelu(hr)
+    ref.backward(g.float())
+    torch.testing.assert_close(ops.gelu_fwd(h).float(), ref.detach(), **_tol(dtype))
+    torch.testing.assert_close(ops.gelu_bwd(h, g).float(), hr.grad, **_tol(dtype))
+
+
+def _ref_attention(q, k, v, mask, causal, keep=None, p=0.0):
+    """BertSelfAttention math (modeling_bert.py:111-136) in f32 on [B,nh,S,64] tensors."""
+    B, nh, Sq, _ = q.shape
+    Sk = k.shape[2]
+    s = q @ k.transpose(-1, -2) / 8.0
+    allow = torch.ones(B, 1, Sq, Sk, dtype=torch.bool, device=q.device)
+    if mask is not None:
+        allow = allow & mask.bool()[:, None, None, :]
+    if causal:
+        allow = allow & torch.ones(Sq, Sk, dtype=torch.bool, device=q.device).tril()[None, None]
+    s = s.masked_fill(~allow, float("-inf"))
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = pr * keep / (1 - p)
+    return pr @ v
+
+
+@pytest.mark.parametrize("B,nh,Sq,Sk,causal,masked", [(3, 12, 32, 32, False, True), (2, 4, 32, 32, True, True), (2, 3, 12, 12, True, True),
+                                                      (2, 2, 7, 32, False, False), (1, 1, 32, 5, False, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_fwd_bwd(ops, B, nh, Sq, Sk, causal, masked, dtype):
+    torch.manual_seed(B * 100 + Sq)
+    H = nh * 64
+    qkv = torch.randn(B * Sq, 3 * H, device="cuda").to(dtype)        # fused QKV layout: strided q/k/v views
+    kv = torch.randn(B * Sk, 2 * H, device="cuda").to(dtype)
+    if Sq == Sk:
+        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    else:
+        q, k, v = qkv[:, :H], kv[:, :H], kv[:, H:]
+    mask = None
+    if masked:
+        lens = torch.randint(1, Sk + 1, (B,), device="cuda")
+        mask = (torch.arange(Sk, device="cuda")[None] < lens[:, None]).long()
+    ctx, lse = ops.attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal)
+    def heads(t, S):
+        return t.float().reshape(B, S, nh, 64).transpose(1, 2).detach().clone().requires_grad_(True)
+    qr, kr, vr = heads(q, Sq), heads(k, Sk), heads(v, Sk)
+    ref = _ref_attention(qr, kr, vr, mask, causal)
+    torch.testing.assert_close(ctx.float(), ref.transpose(1, 2).reshape(B * Sq, H), **_tol(dtype))
+    g = torch.randn(B * Sq, H, device="cuda").to(dtype)
+    ref.backward(g.float().reshape(B, Sq, nh, 64).transpose(1, 2))
+    g_q = torch.empty_like(qkv)[:, :H]; 
+    gbuf_q = torch.zeros_like(qkv); gbuf_kv = torch.zeros_like(kv)
+    if Sq == Sk:
+        gq, gk, gv = gbuf_q[:, :H], gbuf_q[:, H:2 * H], gbuf_q[:, 2 * H:]
+    else:
+        gq, gk, gv = gbuf_q[:, :H], gbuf_kv[:, :H], gbuf_kv[:, H:]
+    ops.attn_bwd(q, k, v, mask, g, B, nh, Sq, Sk, causal, 0.0, 0, 0, gq, gk, gv)
+    unh = lambda t, S: t.transpose(1, 2).reshape(B * S, H)
+    t = _tol(dtype)
+    torch.testing.assert_close(gq.float(), unh(qr.grad, Sq), **t)
+    torch.testing.assert_close(gk.float(), unh(kr.grad, Sk), **t)
+    torch.testing.assert_close(gv.float(), unh(vr.grad, Sk), **t)
+
+
+def test_attention_dropout_mask_consistency(ops):
+    """Reveal the Philox mask with q = 0, V = one-hot rows; then fwd/bwd must match a reference using that mask."""
+    B, nh, S, p = 2, 3, 32, 0.1
+    H = nh * 64
+    q0 = torch.zeros(B * S, H, device="cuda"); k0 = torch.zeros(B * S, H, device="cuda")
+    eye = torch.zeros(S, 64, device="cuda"); eye[torch.arange(S), torch.arange(S)] = 1
+    v1 = eye[None, :, None, :].expand(B, S, nh, 64).reshape(B * S, H).contiguous()
+    ctx, _ = ops.attn_fwd(q0, k0, v1, None, B, nh, S, S, False, p, seed=99, site=3)
+    pt = ctx.reshape(B, S, nh, 64)[..., :S].permute(0, 2, 1, 3)            # P~[b,h,i,j] = keep/(S(1-p))
+    keep = (pt > 0).float()
+    assert abs((1 - keep.mean().item()) - p) < 0.02
+    torch.manual_seed(5)
+    q = torch.randn(B * S, H, device="cuda"); k = torch.randn(B * S, H, device="cuda"); v = torch.randn(B * S, H, device="cuda")
+    g = torch.randn(B * S, H, device="cuda")
+    heads = lambda t: t.reshape(B, S, nh, 64).transpose(1, 2).detach().clone().requires_grad_(True)
+    qr, kr, vr = heads(q), heads(k), heads(v)
+    ref = _ref_attention(qr, kr, vr, None, True, keep, p)
+    ctx, _ = ops.attn_fwd(q, k, v, None, B, nh, S, S, True, p, seed=99, site=3)
+    torch.testing.assert_close(ctx, ref.transpose(1, 2).reshape(B * S, H), rtol=1e-4, atol=1e-5)
+    ref.backward(g.reshape(B, S, nh, 64).transpose(1, 2))
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.attn_bwd(q, k, v, None, g, B, nh, S, S, True, p, 99, 3, gq, gk, gv)
+    unh = lambda t: t.transpose(1, 2).reshape(B * S, H)
+    torch.testing.assert_close(gq, unh(qr.grad), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gk, unh(kr.grad), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gv, unh(vr.grad), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("amsgrad,wd", [(False, 0.0), (True, 0.01)])
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
+def test_adam_matches_torch(ops, amsgrad, wd, gdtype):
+    torch.manual_seed(1)
+    n = 4096 * 3
+    p = torch.randn(n, device="cuda")
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-3, weight_decay=wd, amsgrad=amsgrad)
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    vmax = torch.zeros(n, device="cuda") if amsgrad else None
+    shadow = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    for step in range(1, 6):
+        g = torch.randn(n, device="cuda").to(gdtype)
+        ref_p.grad = g.float().clone()
+        opt.step()
+        ops.adam_step(p, g, m, v, step, 1e-3, weight_decay=wd, vmax=vmax, shadow=shadow)
+        torch.testing.assert_close(p, ref_p.detach(), rtol=2e-6, atol=2e-7)
+    assert torch.equal(shadow, p.bfloat16())
