@@ -1,0 +1,525 @@
+"""TrainEngine -- the MI355X execution plan of one Shelgon / Bagon training step (models/shelgon3/Trainer.py:65-124).
+
+The reference builds an autograd graph of ~2k ATen ops per step and lets torch.optim.Adam walk 400 parameter tensors.
+This engine runs the same mathematics as an explicit forward / backward schedule over FLAT buffers:
+
+  memory    every parameter of the model lives in one f32 master buffer (the nn.Parameters are re-pointed at views
+            of it, so state_dict / checkpoints / the HF modules keep working), mirrored by one bf16 "shadow" buffer the
+            GEMMs read, one bf16 gradient buffer the weight-gradient GEMMs write into directly, and f32 Adam moments.
+            Q/K/V (and cross-attention K/V) weights are adjacent, so the fused [3H,H] projection is a plain view.
+  forward   per block: one GEMM (+bias epilogue) -> one fused kernel (attention core | dropout+residual+LayerNorm | GELU)
+  backward  hand-written mirror of forward; dropout masks are regenerated (Philox), never stored; bias gradients are
+            column sums; weight gradients land in the flat gradient buffer with no accumulate/cast passes
+  update    ONE Adam kernel over the flat buffers that also refreshes the bf16 shadow weights for the next step
+  multi-GPU gradients are laid out in forward order, so backward finishes them from the end of the buffer towards
+            the start: fixed-size tail chunks are all-reduced (RCCL, AVG, bf16) on a side stream while backward continues
+
+GEMMs go through torch.mm / addmm (hipBLASLt, bf16 in / f32 accumulate); everything else is libkvq.so.
+Math restated from HuggingFace modeling_bert.py (see kvq/bert.py for the line map); tests/test_engine_gpu.py checks
+losses and every parameter gradient against the autograd path (kvq.bert + torch autograd).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import nnops
+from ._ffi import KvqError, check, io_dtype_of, lib, stream_ptr
+from .functional import _workspace
+
+V_ALIGN = 64   # vocabulary rows of the LM head are padded so logits rows are 128-byte aligned
+
+
+def _round_up(x, a):
+    return (x + a - 1) // a * a
+
+
+class FlatParams:
+    """Flat master / shadow / gradient / moment buffers over a list of (name, parameter, padded_numel)."""
+
+    def __init__(self, entries: List[Tuple[str, torch.nn.Parameter, int]], device, compute_dtype, amsgrad: bool):
+        self.compute_dtype = compute_dtype
+        self.seg: Dict[str, Tuple[int, int, torch.Size]] = {}
+        self.trainable: Dict[str, bool] = {}
+        off = 0
+        for name, p, padded in entries:
+            self.seg[name] = (off, p.numel(), p.shape)
+            self.trainable[name] = p.requires_grad
+            off += _round_up(padded, 8)
+        self.n = _round_up(off, 8)
+        self.master = torch.zeros(self.n, dtype=torch.float32, device=device)
+        for name, p, _ in entries:
+            o, n, shape = self.seg[name]
+            self.master[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.master[o:o + n].view(shape)          # the module's parameter IS the master copy now
+        if compute_dtype == torch.float32:
+            self.shadow = self.master
+        else:
+            self.shadow = self.master.to(compute_dtype)
+        self.grad = torch.zeros(self.n, dtype=compute_dtype, device=device)
+        self.m = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.vmax = torch.zeros(self.n, dtype=torch.float32, device=device) if amsgrad else None
+        # contiguous trainable ranges (Adam is launched once per range; one range in `full` mode)
+        self.ranges: List[Tuple[int, int]] = []
+        for name, p, padded in entries:
+            if not p.requires_grad:
+                continue
+            o = self.seg[name][0]
+            e = o + _round_up(padded, 8)
+            if self.ranges and self.ranges[-1][1] == o:
+                self.ranges[-1] = (self.ranges[-1][0], e)
+            else:
+                self.ranges.append((o, e))
+
+    def w(self, name, rows=None):
+        o, n, shape = self.seg[name]
+        if rows is not None:                                       # padded 2-D view [rows, shape[1]]
+            return self.shadow[o:o + rows * shape[1]].view(rows, shape[1])
+        return self.shadow[o:o + n].view(shape)
+
+    def g(self, name, rows=None):
+        o, n, shape = self.seg[name]
+        if rows is not None:
+            return self.grad[o:o + rows * shape[-1]].view(rows, shape[-1]) if len(shape) > 1 else self.grad[o:o + rows]
+        return self.grad[o:o + n].view(shape)
+
+    def w32(self, name):
+        o, n, shape = self.seg[name]
+        return self.master[o:o + n].view(shape)
+
+    def fused(self, names, buf):
+        """View spanning adjacent segments (e.g. q,k,v weights) as one [sum rows, cols] matrix / [sum] vector."""
+        o0, _, shape0 = self.seg[names[0]]
+        total = 0
+        for nm in names:
+            o, n, _ = self.seg[nm]
+            assert o == o0 + total, f"segments {names} are not adjacent"
+            total += n
+        flat = buf[o0:o0 + total]
+        return flat.view(-1, shape0[1]) if len(shape0) == 2 else flat
+
+    def refresh_shadow(self):
+        if self.shadow is not self.master:
+            self.shadow.copy_(self.master)
+
+
+class TrainEngine:
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False,
+                 milestones=None, gamma=0.1, loss_recon_scale=1.0, loss_vq_scale=1.0, seed=1234,
+                 bucket_mib=64, process_group=None):
+        self.model = model
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise KvqError("TrainEngine needs the model on an MI355X (there is no CPU path)")
+        lib()
+        self.dev = dev
+        self.dtype = model.compute_dtype
+        self.io = 1 if self.dtype == torch.bfloat16 else 0
+        self.has_vq = hasattr(model, "vector_quantizer")
+        enc, dec = model.encoder, model.decoder
+        self.ecfg, self.dcfg = enc.config, dec.config
+        if self.ecfg.hidden_size // self.ecfg.num_attention_heads != 64:
+            raise KvqError("TrainEngine: attention kernels are written for head dim 64")
+        self.H = self.ecfg.hidden_size
+        self.V = self.dcfg.vocab_size
+        self.Vp = _round_up(self.V, V_ALIGN)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.milestones, self.gamma = sorted(milestones or []), gamma
+        self.w_recon, self.w_vq = float(loss_recon_scale), float(loss_vq_scale)
+        self.seed, self.step_count = int(seed), 0
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+
+        # ---- flat parameter layout, in FORWARD order (gradients then complete from the tail backwards)
+        entries, seen = [], set()
+        self.param_of: Dict[str, torch.nn.Parameter] = {}
+
+        def add(name, p, padded=None):
+            if id(p) in seen:
+                return
+            seen.add(id(p))
+            self.param_of[name] = p
+            entries.append((name, p, padded if padded is not None else p.numel()))
+
+        def add_emb(prefix, emb, pad_word_rows=None):
+            w = emb.word_embeddings.weight
+            add(prefix + "word", w, (pad_word_rows or w.shape[0]) * w.shape[1])
+            add(prefix + "pos", emb.position_embeddings.weight)
+            add(prefix + "type", emb.token_type_embeddings.weight)
+            add(prefix + "ln.w", emb.LayerNorm.weight); add(prefix + "ln.b", emb.LayerNorm.bias)
+
+        def add_attn(prefix, att, cross):
+            s = att.self
+            if cross:
+                add(prefix + "q.w", s.query.weight)
+                add(prefix + "k.w", s.key.weight); add(prefix + "v.w", s.value.weight)
+                add(prefix + "q.b", s.query.bias)
+                add(prefix + "k.b", s.key.bias); add(prefix + "v.b", s.value.bias)
+            else:
+                add(prefix + "q.w", s.query.weight); add(prefix + "k.w", s.key.weight); add(prefix + "v.w", s.value.weight)
+                add(prefix + "q.b", s.query.bias); add(prefix + "k.b", s.key.bias); add(prefix + "v.b", s.value.bias)
+            add(prefix + "o.w", att.output.dense.weight); add(prefix + "o.b", att.output.dense.bias)
+            add(prefix + "ln.w", att.output.LayerNorm.weight); add(prefix + "ln.b", att.output.LayerNorm.bias)
+
+        def add_layer(prefix, layer, cross):
+            add_attn(prefix + "sa.", layer.attention, False)
+            if cross:
+                add_attn(prefix + "ca.", layer.crossattention, True)
+            add(prefix + "f1.w", layer.intermediate.dense.weight); add(prefix + "f1.b", layer.intermediate.dense.bias)
+            add(prefix + "f2.w", layer.output.dense.weight); add(prefix + "f2.b", layer.output.dense.bias)
+            add(prefix + "ln2.w", layer.output.LayerNorm.weight); add(prefix + "ln2.b", layer.output.LayerNorm.bias)
+
+        add_emb("enc.emb.", enc.embeddings)
+        for i, layer in enumerate(enc.encoder.layer):
+            add_layer(f"enc.{i}.", layer, False)
+        add_emb("dec.emb.", dec.bert.embeddings, pad_word_rows=self.Vp)     # tied to the LM head: padded to Vp rows
+        for i, layer in enumerate(dec.bert.encoder.layer):
+            add_layer(f"dec.{i}.", layer, True)
+        head = dec.cls.predictions
+        add("head.t.w", head.transform.dense.weight); add("head.t.b", head.transform.dense.bias)
+        add("head.ln.w", head.transform.LayerNorm.weight); add("head.ln.b", head.transform.LayerNorm.bias)
+        add("head.bias", head.decoder.bias, self.Vp)
+        if head.decoder.weight is not dec.bert.embeddings.word_embeddings.weight:
+            raise KvqError("TrainEngine expects the LM head tied to the decoder word embeddings (HF default)")
+        # parameters the step never touches (pooler) stay outside the flat buffers and receive no gradient
+        self.flat = FlatParams(entries, dev, self.dtype, amsgrad)
+        self.n_enc_layers = len(enc.encoder.layer)
+        self.n_dec_layers = len(dec.bert.encoder.layer)
+        self.nh = self.ecfg.num_attention_heads
+        if self.has_vq:
+            vq = model.vector_quantizer
+            self.E = vq.embedding.weight                      # f32 parameter, own tiny Adam state (f32 gradient)
+            self.gE = torch.zeros_like(self.E.data)
+            self.mE = torch.zeros_like(self.E.data); self.vE = torch.zeros_like(self.E.data)
+            self.vmaxE = torch.zeros_like(self.E.data) if amsgrad else None
+            self.beta_vq = float(vq.beta)
+        # gradient all-reduce chunks (tail first)
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self._avg_in_comm = self.world > 1 and dist.get_backend(process_group) == "nccl"   # RCCL averages itself; gloo sums
+        self.chunk = bucket_mib * (1 << 20) // self.flat.grad.element_size()
+        self._pending_hi = self.flat.n
+        self._works = []
+        self._ones = torch.ones((), dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # small helpers
+    # ------------------------------------------------------------------------------------------------------------
+    def _lr_now(self):
+        k = sum(1 for m in self.milestones if self.step_count >= m)
+        return self.lr * (self.gamma ** k)
+
+    def _site(self):
+        self._site_ctr += 1
+        return self._site_ctr
+
+    def _linear(self, x, wname, bname, fused=None):
+        W = self.flat.fused(fused[0], self.flat.shadow) if fused else self.flat.w(wname)
+        b = self.flat.fused(fused[1], self.flat.shadow) if fused else self.flat.w(bname)
+        return torch.addmm(b, x, W.t())
+
+    def _linear_bwd(self, gy, x, wnames, bnames, need_gx=True, gx_accum=None):
+        """Weight / bias gradients straight into the flat gradient buffer; returns gx (or accumulates into gx_accum)."""
+        fl = self.flat
+        if len(wnames) == 1:
+            W, gW, gb = fl.w(wnames[0]), fl.g(wnames[0]), fl.g(bnames[0])
+        else:
+            W, gW, gb = fl.fused(wnames, fl.shadow), fl.fused(wnames, fl.grad), fl.fused(bnames, fl.grad)
+        if fl.trainable[wnames[0]]:
+            torch.mm(gy.t(), x, out=gW)
+        if fl.trainable[bnames[0]]:
+            nnops.colsum(gy, gb)
+        if gx_accum is not None:
+            gx_accum.addmm_(gy, W)
+            return gx_accum
+        return torch.mm(gy, W) if need_gx else None
+
+    # ------------------------------------------------------------------------------------------------------------
+    # blocks: forward returns (output, saved); backward consumes saved
+    # ------------------------------------------------------------------------------------------------------------
+    def _emb_fwd(self, prefix, cfg, ids, training, word_rows=None):
+        fl = self.flat
+        B, S = ids.shape
+        word = fl.w(prefix + "word", rows=word_rows) if word_rows else fl.w(prefix + "word")
+        y = F.embedding(ids.reshape(-1), word)                                           # [N,H]
+        pt = (fl.w(prefix + "pos")[:S] + fl.w(prefix + "type")[0]).repeat(B, 1)          # [N,H]
+        out, pre, mean, rstd = nnops.ln_fwd(y, pt, fl.w32(prefix + "ln.w"), fl.w32(prefix + "ln.b"), cfg.layer_norm_eps)
+        keep = None
+        p = cfg.hidden_dropout_prob if training else 0.0
+        if p > 0:
+            keep = (torch.rand_like(out, dtype=torch.float32) >= p).to(out.dtype) * (1.0 / (1.0 - p))
+            out = out * keep
+        return out, (ids, pre, mean, rstd, keep)
+
+    def _emb_bwd(self, prefix, g, saved, tied_accumulate=False):
+        fl = self.flat
+        ids, pre, mean, rstd, keep = saved
+        B, S = ids.shape
+        if keep is not None:
+            g = g * keep
+        tr = fl.trainable
+        g_y, g_pt = nnops.ln_bwd(g, pre, mean, rstd, fl.w32(prefix + "ln.w"),
+                                 g_gamma=fl.g(prefix + "ln.w") if tr[prefix + "ln.w"] else None,
+                                 g_beta=fl.g(prefix + "ln.b") if tr[prefix + "ln.b"] else None)
+        if tr[prefix + "word"]:
+            o, n, shape = fl.seg[prefix + "word"]
+            acc = torch.zeros(shape, dtype=torch.float32, device=self.dev)
+            acc.index_add_(0, ids.reshape(-1), g_y.float())
+            gw = fl.grad[o:o + n].view(shape)
+            if tied_accumulate:
+                gw.add_(acc.to(gw.dtype))          # LM-head weight gradient is already in there
+            else:
+                gw.copy_(acc)
+        if tr[prefix + "pos"]:
+            gp = fl.g(prefix + "pos")
+            gp.zero_()
+            gp[:S] = g_pt.view(B, S, -1).float().sum(0).to(gp.dtype)
+        if tr[prefix + "type"]:
+            gt = fl.g(prefix + "type")
+            gt.zero_()
+            gt[0] = g_pt.float().sum(0).to(gt.dtype)
+
+    def _attn_block_fwd(self, pre, x, kv_src, mask, causal, cfg, training, B, Sq, Sk):
+        """self-attention (kv_src is None) or cross-attention on kv_src; returns LN(dropout(dense(ctx)) + x)."""
+        fl, H, nh = self.flat, self.H, self.nh
+        p_attn = cfg.attention_probs_dropout_prob if training else 0.0
+        p_hid = cfg.hidden_dropout_prob if training else 0.0
+        site_a, site_o = self._site(), self._site()
+        if kv_src is None:
+            qkv = self._linear(x, None, None, fused=([pre + "q.w", pre + "k.w", pre + "v.w"], [pre + "q.b", pre + "k.b", pre + "v.b"]))
+            q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+            kvbuf = None
+        else:
+            qkv = self._linear(x, pre + "q.w", pre + "q.b")
+            kvbuf = self._linear(kv_src, None, None, fused=([pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"]))
+            q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
+        ctx, _ = nnops.attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a)
+        ao = self._linear(ctx, pre + "o.w", pre + "o.b")
+        out, lnpre, mean, rstd = nnops.ln_fwd(ao, x, fl.w32(pre + "ln.w"), fl.w32(pre + "ln.b"), cfg.layer_norm_eps,
+                                              p_hid, self._step_seed, site_o)
+        return out, (x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk)
+
+    def _attn_block_bwd(self, pre, g_out, saved, g_kv_src=None):
+        """returns g_x; for cross-attention accumulates the gradient of kv_src into g_kv_src."""
+        fl, H, nh = self.flat, self.H, self.nh
+        x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk = saved
+        tr = fl.trainable
+        g_ao, g_x = nnops.ln_bwd(g_out, lnpre, mean, rstd, fl.w32(pre + "ln.w"), p_hid, self._step_seed, site_o,
+                                 g_gamma=fl.g(pre + "ln.w") if tr[pre + "ln.w"] else None,
+                                 g_beta=fl.g(pre + "ln.b") if tr[pre + "ln.b"] else None)
+        g_ctx = self._linear_bwd(g_ao, ctx, [pre + "o.w"], [pre + "o.b"])
+        g_qkv = torch.empty_like(qkv)
+        if kv_src is None:
+            q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+            nnops.attn_bwd(q, k, v, mask, g_ctx, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a,
+                           g_qkv[:, :H], g_qkv[:, H:2 * H], g_qkv[:, 2 * H:])
+            self._linear_bwd(g_qkv, x, [pre + "q.w", pre + "k.w", pre + "v.w"], [pre + "q.b", pre + "k.b", pre + "v.b"], gx_accum=g_x)
+        else:
+            g_kv = torch.empty_like(kvbuf)
+            nnops.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], mask, g_ctx, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a,
+                           g_qkv, g_kv[:, :H], g_kv[:, H:])
+            self._linear_bwd(g_qkv, x, [pre + "q.w"], [pre + "q.b"], gx_accum=g_x)
+            self._linear_bwd(g_kv, kv_src, [pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"], gx_accum=g_kv_src)
+        return g_x
+
+    def _ffn_fwd(self, pre, x, cfg, training):
+        fl = self.flat
+        p_hid = cfg.hidden_dropout_prob if training else 0.0
+        site = self._site()
+        h = self._linear(x, pre + "f1.w", pre + "f1.b")
+        a = nnops.gelu_fwd(h)
+        f = self._linear(a, pre + "f2.w", pre + "f2.b")
+        out, lnpre, mean, rstd = nnops.ln_fwd(f, x, fl.w32(pre + "ln2.w"), fl.w32(pre + "ln2.b"), cfg.layer_norm_eps,
+                                              p_hid, self._step_seed, site)
+        return out, (x, h, a, lnpre, mean, rstd, p_hid, site)
+
+    def _ffn_bwd(self, pre, g_out, saved):
+        fl = self.flat
+        x, h, a, lnpre, mean, rstd, p_hid, site = saved
+        tr = fl.trainable
+        g_f, g_x = nnops.ln_bwd(g_out, lnpre, mean, rstd, fl.w32(pre + "ln2.w"), p_hid, self._step_seed, site,
+                                g_gamma=fl.g(pre + "ln2.w") if tr[pre + "ln2.w"] else None,
+                                g_beta=fl.g(pre + "ln2.b") if tr[pre + "ln2.b"] else None)
+        g_a = self._linear_bwd(g_f, a, [pre + "f2.w"], [pre + "f2.b"])
+        g_h = nnops.gelu_bwd(h, g_a, out=g_a)
+        self._linear_bwd(g_h, x, [pre + "f1.w"], [pre + "f1.b"], gx_accum=g_x)
+        return g_x
+
+    # ------------------------------------------------------------------------------------------------------------
+    # gradient exchange (multi-GPU): all-reduce finished tail chunks of the flat gradient buffer while backward runs
+    # ------------------------------------------------------------------------------------------------------------
+    def _grads_done_down_to(self, name):
+        """Every gradient located at or after segment `name` is final."""
+        if self.world == 1:
+            return
+        lo = self.flat.seg[name][0]
+        while self._pending_hi - self.chunk >= lo:
+            self._reduce(self._pending_hi - self.chunk, self._pending_hi)
+            self._pending_hi -= self.chunk
+
+    def _all_reduce_avg(self, t):
+        self.comm_stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.comm_stream):
+            if self._avg_in_comm:
+                self._works.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+            else:
+                self._works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
+
+    def _reduce(self, a, b):
+        self._all_reduce_avg(self.flat.grad[a:b])
+
+    def _grads_finish(self):
+        if self.world == 1:
+            return
+        if self._pending_hi > 0:
+            self._reduce(0, self._pending_hi)
+        if self.has_vq:
+            self._all_reduce_avg(self.gE)
+        for w, t in self._works:
+            w.wait()
+            if t is not None:
+                with torch.cuda.stream(self.comm_stream):
+                    t.div_(self.world)
+        self._works = []
+        torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
+        self._pending_hi = self.flat.n
+
+    # ------------------------------------------------------------------------------------------------------------
+    # one training step
+    # ------------------------------------------------------------------------------------------------------------
+    def forward_backward(self, input_ids, attention_mask, training=True, compute_grads=True):
+        """Forward (+ backward when compute_grads).  Returns dict(loss_recon, loss_vq, perplexity, acc, recon_ids, indices)."""
+        m = self.model
+        fl, H = self.flat, self.H
+        B, S = input_ids.shape
+        N = B * S
+        if S > 32:
+            raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
+        self._site_ctr = 0
+        self._step_seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
+        mask = attention_mask.contiguous()
+        ecfg, dcfg = self.ecfg, self.dcfg
+
+        # ---------------- forward ----------------
+        x, emb_saved = self._emb_fwd("enc.emb.", ecfg, input_ids, training)
+        enc_saved = []
+        for i in range(self.n_enc_layers):
+            x, sa = self._attn_block_fwd(f"enc.{i}.sa.", x, None, mask, False, ecfg, training, B, S, S)
+            x, ff = self._ffn_fwd(f"enc.{i}.", x, ecfg, training)
+            enc_saved.append((sa, ff))
+        z = x
+        if self.has_vq:
+            ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, self.E.shape[0], H, 1))
+            z_q = torch.empty_like(z)
+            idx = torch.empty(N, dtype=torch.int64, device=self.dev)
+            vq_out = torch.empty(2, dtype=torch.float32, device=self.dev)
+            check(lib().kvq_vq_forward(z.data_ptr(), self.E.data_ptr(), N, self.E.shape[0], H, 1, self.io, self.beta_vq,
+                                       z_q.data_ptr(), idx.data_ptr(), vq_out[0:].data_ptr(), vq_out[1:].data_ptr(), None,
+                                       ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward")
+            loss_vq, perplexity = vq_out[0], vq_out[1]
+            enc_out = z_q
+        else:
+            idx, loss_vq, perplexity, enc_out = None, None, None, z
+
+        y, demb_saved = self._emb_fwd("dec.emb.", dcfg, input_ids, training, word_rows=None)
+        dec_saved = []
+        for i in range(self.n_dec_layers):
+            y, sa = self._attn_block_fwd(f"dec.{i}.sa.", y, None, mask, True, dcfg, training, B, S, S)
+            y, ca = self._attn_block_fwd(f"dec.{i}.ca.", y, enc_out, None, False, dcfg, training, B, S, S)
+            y, ff = self._ffn_fwd(f"dec.{i}.", y, dcfg, training)
+            dec_saved.append((sa, ca, ff))
+        t = self._linear(y, "head.t.w", "head.t.b")
+        ta = nnops.gelu_fwd(t)
+        hN, hpre, hmean, hrstd = nnops.ln_fwd(ta, None, fl.w32("head.ln.w"), fl.w32("head.ln.b"), dcfg.layer_norm_eps)
+        Wv = fl.w("dec.emb.word", rows=self.Vp)                              # [Vp,H], rows >= V are zero
+        bv = fl.shadow[fl.seg["head.bias"][0]: fl.seg["head.bias"][0] + self.Vp]
+        logits = torch.addmm(bv, hN, Wv.t())                                  # [N,Vp]
+        tgt = input_ids.reshape(-1)
+        row_loss = torch.empty(N, dtype=torch.float32, device=self.dev)
+        row_lse = torch.empty(N, dtype=torch.float32, device=self.dev)
+        pred = torch.empty(N, dtype=torch.int64, device=self.dev)
+        ce_out = torch.empty(2, dtype=torch.float32, device=self.dev)
+        check(lib().kvq_ce_forward(logits.data_ptr(), tgt.data_ptr(), N, self.V, self.Vp, self.io, row_loss.data_ptr(),
+                                   row_lse.data_ptr(), pred.data_ptr(), ce_out[0:].data_ptr(), ce_out[1:].data_ptr(), stream_ptr()),
+              "kvq_ce_forward")
+        out = dict(loss_recon=ce_out[0] * self.w_recon, loss_vq=(loss_vq * self.w_vq) if self.has_vq else None,
+                   perplexity=perplexity, acc=ce_out[1], recon_ids=pred.view(B, S), indices=idx.view(B, S, 1) if idx is not None else None)
+        if not compute_grads:
+            return out
+
+        # ---------------- backward ----------------
+        tr = fl.trainable
+        g_scale = self._ones * self.w_recon
+        check(lib().kvq_ce_backward(logits.data_ptr(), tgt.data_ptr(), row_lse.data_ptr(), g_scale.data_ptr(), N, self.V, self.Vp,
+                                    self.io, logits.data_ptr(), stream_ptr()), "kvq_ce_backward")      # in place: logits := d loss / d logits
+        g_logits = logits
+        if tr["head.bias"]:
+            nnops.colsum(g_logits, fl.g("head.bias", rows=self.Vp))
+        if tr["dec.emb.word"]:
+            torch.mm(g_logits.t(), hN, out=fl.g("dec.emb.word", rows=self.Vp))
+        g_hN = torch.mm(g_logits, Wv)
+        del logits, g_logits
+        g_ta, _ = nnops.ln_bwd(g_hN, hpre, hmean, hrstd, fl.w32("head.ln.w"),
+                               g_gamma=fl.g("head.ln.w") if tr["head.ln.w"] else None,
+                               g_beta=fl.g("head.ln.b") if tr["head.ln.b"] else None, need_g_resid=False)
+        g_t = nnops.gelu_bwd(t, g_ta, out=g_ta)
+        g_y = self._linear_bwd(g_t, y, ["head.t.w"], ["head.t.b"])
+        self._grads_done_down_to("head.t.w")
+        g_enc = torch.zeros_like(enc_out)
+        for i in reversed(range(self.n_dec_layers)):
+            sa, ca, ff = dec_saved[i]
+            g_y = self._ffn_bwd(f"dec.{i}.", g_y, ff)
+            g_y = self._attn_block_bwd(f"dec.{i}.ca.", g_y, ca, g_kv_src=g_enc)
+            g_y = self._attn_block_bwd(f"dec.{i}.sa.", g_y, sa)
+            self._grads_done_down_to(f"dec.{i}.sa.q.w")
+            dec_saved[i] = None
+        self._emb_bwd("dec.emb.", g_y, demb_saved, tied_accumulate=True)
+        self._grads_done_down_to("dec.emb.word")
+        if self.has_vq:
+            g_z = torch.empty_like(z)
+            gl = self._ones * self.w_vq
+            ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, self.E.shape[0], H, 1))
+            need_E = self.E.requires_grad
+            check(lib().kvq_vq_backward(z.data_ptr(), self.E.data_ptr(), idx.data_ptr(), g_enc.data_ptr(), gl.data_ptr(), N,
+                                        self.E.shape[0], H, 1, self.io, self.beta_vq, g_z.data_ptr(),
+                                        self.gE.data_ptr() if need_E else None, ws.data_ptr(), ws.numel(), stream_ptr()),
+                  "kvq_vq_backward")
+            g_x = g_z
+        else:
+            g_x = g_enc
+        any_enc = any(v for k, v in tr.items() if k.startswith("enc."))
+        if any_enc:
+            for i in reversed(range(self.n_enc_layers)):
+                sa, ff = enc_saved[i]
+                g_x = self._ffn_bwd(f"enc.{i}.", g_x, ff)
+                g_x = self._attn_block_bwd(f"enc.{i}.sa.", g_x, sa)
+                self._grads_done_down_to(f"enc.{i}.sa.q.w")
+                enc_saved[i] = None
+            self._emb_bwd("enc.emb.", g_x, emb_saved)
+        return out
+
+    def optimizer_step(self):
+        self._grads_finish()
+        self.step_count += 1
+        lr = self._lr_now()
+        fl = self.flat
+        b1, b2 = self.betas
+        for (a, b) in fl.ranges:
+            nnops.adam_step(fl.master[a:b], fl.grad[a:b], fl.m[a:b], fl.v[a:b], self.step_count, lr, b1, b2, self.eps, self.wd,
+                            vmax=fl.vmax[a:b] if fl.vmax is not None else None,
+                            shadow=fl.shadow[a:b] if fl.shadow is not fl.master else None)
+        if self.has_vq and self.E.requires_grad:
+            nnops.adam_step(self.E.data.view(-1), self.gE.view(-1), self.mE.view(-1), self.vE.view(-1), self.step_count, lr,
+                            b1, b2, self.eps, self.wd, vmax=self.vmaxE.view(-1) if self.vmaxE is not None else None)
+
+    def train_step(self, input_ids, attention_mask):
+        out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True)
+        self.optimizer_step()
+        return out
+
+    def eval_step(self, input_ids, attention_mask):
+        return self.forward_backward(input_ids, attention_mask, training=False, compute_grads=False)

@@ -29,7 +29,7 @@ SUPPORTED_MODEL_MODES = ["full", "dec-head-ft", "enc-head-ft-dec-head-ft", "vq-f
 LOCAL_BERT_CONFIGS = {
     "bert-base-uncased": dict(),   # BertConfig() defaults ARE bert-base: 768/12/12/3072, vocab 30522, 512 positions
     "kvq-bert-small": dict(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024),
-    "kvq-bert-tiny": dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+    "kvq-bert-tiny": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                           vocab_size=2048, max_position_embeddings=64),
 }
 

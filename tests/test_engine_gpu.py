@@ -1,0 +1,130 @@
+"""The explicit forward/backward TrainEngine against the autograd path (kvq.bert + torch autograd) on the same model:
+losses, every parameter gradient, and the Adam update.  f32 compute with dropout off for tight tolerances; bf16 for the
+production dtype."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(dtype, mode="full", K=32):
+    from models.shelgon3.Shelgon import Shelgon
+    from models.shelgon3.VectorQuantizer import VectorQuantizer
+    torch.manual_seed(0)
+    vq = VectorQuantizer(K, 128, 0.25, vq_codebook_init_values=torch.randn(K, 128))
+    vq.materialize_min_encodings = False
+    model = Shelgon("kvq-bert-tiny", vq, "kvq-bert-tiny", None, compute_dtype=dtype).cuda()
+    model.set_mode(mode)
+    return model
+
+
+def _batch(B=6, S=12, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1000, 2000, (B, S), generator=g)
+    lens = torch.randint(3, S + 1, (B,), generator=g)
+    ids = ids * (torch.arange(S)[None] < lens[:, None])
+    return ids.cuda(), (ids != 0).long().cuda()
+
+
+def _autograd_reference(model, ids, mask):
+    model.eval()                                  # dropout off; the engine is run with training=False as well
+    for p in model.parameters():
+        p.grad = None
+    l_vq, perp, idx, l_rec, acc, recon = model.forward_loss(ids, mask)
+    (l_rec + l_vq).backward()
+    return dict(loss_recon=l_rec.item(), loss_vq=l_vq.item(), perp=perp.item(), acc=acc.item(), idx=idx.clone(), recon=recon.clone())
+
+
+@pytest.mark.parametrize("mode", ["full", "dec-head-ft", "enc-head-ft-dec-head-ft"])
+def test_engine_f32_matches_autograd(mode):
+    from kvq.engine import TrainEngine
+    model = _build(torch.float32, mode)
+    ids, mask = _batch()
+    eng = TrainEngine(model, lr=1e-3)
+    ref = _autograd_reference(model, ids, mask)
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+    np.testing.assert_allclose(out["loss_recon"].item(), ref["loss_recon"], rtol=2e-5)
+    np.testing.assert_allclose(out["loss_vq"].item(), ref["loss_vq"], rtol=2e-5)
+    np.testing.assert_allclose(out["perplexity"].item(), ref["perp"], rtol=1e-4)
+    assert torch.equal(out["indices"], ref["idx"]) and torch.equal(out["recon_ids"], ref["recon"])
+    checked = 0
+    for name, p in eng.param_of.items():
+        if not p.requires_grad:
+            continue
+        g = eng.flat.g(name).float()
+        assert p.grad is not None, name
+        torch.testing.assert_close(g, p.grad, rtol=2e-3, atol=2e-6, msg=lambda m: f"{name}: {m}")
+        checked += 1
+    assert checked > 10
+    torch.testing.assert_close(eng.gE, model.vector_quantizer.embedding.weight.grad, rtol=1e-4, atol=1e-8)
+
+
+def test_engine_adam_step_matches_torch_adam():
+    from kvq.engine import TrainEngine
+    model = _build(torch.float32)
+    ref_model = copy.deepcopy(model)
+    ids, mask = _batch(seed=3)
+    eng = TrainEngine(model, lr=1e-3, weight_decay=0.01, amsgrad=True, milestones=[2], gamma=0.5)
+    opt = torch.optim.Adam(ref_model.parameters(), lr=1e-3, weight_decay=0.01, amsgrad=True)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2], gamma=0.5)
+    model.eval(); ref_model.eval()
+    for _ in range(3):
+        out = eng.train_step(ids, mask)
+        opt.zero_grad()
+        l_vq, _, _, l_rec, _, _ = ref_model.forward_loss(ids, mask)
+        (l_rec + l_vq).backward()
+        opt.step(); sched.step()
+        np.testing.assert_allclose(out["loss_recon"].item(), l_rec.item(), rtol=1e-4)
+    ref_params = dict(ref_model.named_parameters())
+    for name, p in model.named_parameters():
+        if "pooler" in name:
+            continue
+        torch.testing.assert_close(p.data, ref_params[name].data, rtol=1e-3, atol=2e-5, msg=lambda m: f"{name}: {m}")
+
+
+def test_engine_bf16_close_to_f32_autograd():
+    from kvq.engine import TrainEngine
+    model32 = _build(torch.float32)
+    ids, mask = _batch(B=8, S=32, seed=5)
+    ref = _autograd_reference(model32, ids, mask)
+    model = _build(torch.bfloat16)
+    eng = TrainEngine(model, lr=1e-3)
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+    np.testing.assert_allclose(out["loss_recon"].item(), ref["loss_recon"], rtol=2e-2)
+    np.testing.assert_allclose(out["loss_vq"].item(), ref["loss_vq"], rtol=5e-2)
+    p32 = dict(model32.named_parameters())
+    cos = []
+    for name, p in eng.param_of.items():
+        ref_name = [n for n, q in model.named_parameters() if q is p][0]
+        g = eng.flat.g(name).float().reshape(-1)
+        r = p32[ref_name].grad.reshape(-1)
+        if r.norm() > 0:
+            cos.append(torch.nn.functional.cosine_similarity(g, r, dim=0).item())
+    assert min(cos) > 0.9 and np.mean(cos) > 0.99, (min(cos), np.mean(cos))
+
+
+def test_engine_training_reduces_loss_with_dropout():
+    from kvq.engine import TrainEngine
+    model = _build(torch.bfloat16).train()
+    eng = TrainEngine(model, lr=2e-3)
+    ids, mask = _batch(B=16, S=32, seed=7)
+    losses = [float(eng.train_step(ids, mask)["loss_recon"]) for _ in range(30)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses[::5]
+    a = eng.forward_backward(ids, mask, training=True, compute_grads=False)["loss_recon"].item()
+    b = eng.forward_backward(ids, mask, training=True, compute_grads=False)["loss_recon"].item()
+    assert a == b        # same step seed -> same dropout masks: the step is reproducible
+    state = model.state_dict()
+    assert "vector_quantizer.embedding.weight" in state and "encoder.embeddings.word_embeddings.weight" in state
+
+
+def test_engine_rejects_long_sequences():
+    from kvq._ffi import KvqError
+    from kvq.engine import TrainEngine
+    model = _build(torch.bfloat16)
+    eng = TrainEngine(model)
+    ids = torch.randint(1000, 2000, (2, 40)).cuda()
+    with pytest.raises(KvqError):
+        eng.train_step(ids, torch.ones_like(ids))
