@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--bucket-mib", type=int, default=64)
+    ap.add_argument("--path", default="engine", choices=["engine", "autograd"],
+                    help="engine = kvq.engine.TrainEngine (explicit fwd/bwd over flat buffers); autograd = kvq.bert + torch autograd")
     return ap.parse_args()
 
 
@@ -76,10 +78,16 @@ def main():
     model.set_mode(a.mode)
     model.train()                      # the reference trains with dropout on (Trainer.py:310)
     ddp.broadcast_parameters(model)
-    params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=0.0, amsgrad=False, fused=True)
-    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10000, 20000], gamma=0.1)
-    sync = ddp.GradSync(params, bucket_mib=a.bucket_mib) if world > 1 else None
+    engine = None
+    if a.path == "engine":
+        from kvq.engine import TrainEngine
+        engine = TrainEngine(model, lr=1e-4, weight_decay=0.0, amsgrad=False, milestones=[10000, 20000], gamma=0.1,
+                             bucket_mib=a.bucket_mib)
+    else:
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-4, weight_decay=0.0, amsgrad=False, fused=True)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[10000, 20000], gamma=0.1)
+        sync = ddp.GradSync(params, bucket_mib=a.bucket_mib) if world > 1 else None
 
     # synthetic dSentences-like ids, resident in HBM before the timed region (BASELINE.md §3 recipe)
     gen = torch.Generator().manual_seed(69 + rank)
@@ -87,6 +95,9 @@ def main():
 
     def one_step(i):
         ids, mask = pool[i % len(pool)]
+        if engine is not None:
+            out = engine.train_step(ids, mask)
+            return out["loss_recon"] + out["loss_vq"]
         loss_vq, perp, _idx, loss_recon, acc, _recon = model.forward_loss(ids, mask)
         loss = loss_recon + loss_vq
         if sync is not None:
@@ -151,7 +162,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": f"Bagon VQ (Shelgon) {a.model} enc/dec, K={a.codes} D={D} seq_len={a.seq_len} "
-                                   f"batch={a.batch}/GPU, mode={a.mode}, Adam, dropout on",
+                                   f"batch={a.batch}/GPU, mode={a.mode}, Adam, dropout on, path={a.path}",
                        "global_batch": world * a.batch, "seq_len": a.seq_len, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
             "roofline": {

@@ -208,36 +208,70 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CS_ROWS = 128;   // rows per partial block
 
+// grid (ceil(C/256), ceil(N/CS_ROWS)), 256 threads: each WAVE streams whole 64x4-column row segments (512 B of bf16,
+// 1 KiB of f32 per row: fully coalesced), waves interleave rows, then the 4 waves are summed through LDS.
 template <int DT_IN>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ x, int64_t N, int64_t C,
                                                               int64_t ld, float* __restrict__ part) {
-    // grid (ceil(C/1024), ceil(N/CS_ROWS)); thread owns 4 consecutive columns
-    const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c0 >= C) return;
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * 4;
     const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
     const int64_t r1 = r0 + CS_ROWS < N ? r0 + CS_ROWS : N;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    const bool vec = (c0 + 4 <= C) && (((size_t)ld * IO<DT_IN>::bytes) % (4 * IO<DT_IN>::bytes) == 0) &&
-                     ((((uintptr_t)x) + (size_t)c0 * IO<DT_IN>::bytes) % (4 * IO<DT_IN>::bytes) == 0);
-    if (vec) {
-        for (int64_t r = r0; r < r1; ++r) a += IO<DT_IN>::load4(x, (size_t)r * ld + c0);
-    } else {
-        for (int64_t r = r0; r < r1; ++r)
-            for (int u = 0; u < 4 && c0 + u < C; ++u) a[u] += IO<DT_IN>::load1(x, (size_t)r * ld + c0 + u);
+    if (c0 < C) {
+        const bool vec = (c0 + 4 <= C) && (ld % 4 == 0) &&
+                         ((((uintptr_t)x) + (size_t)c0 * IO<DT_IN>::bytes) % (4 * IO<DT_IN>::bytes) == 0);
+        if (vec) {
+            f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a3 = {0.f, 0.f, 0.f, 0.f};
+            int64_t r = r0 + w;
+            for (; r + 12 < r1; r += 16) {       // 4 independent loads in flight per lane
+                a += IO<DT_IN>::load4(x, (size_t)r * ld + c0);
+                a1 += IO<DT_IN>::load4(x, (size_t)(r + 4) * ld + c0);
+                a2 += IO<DT_IN>::load4(x, (size_t)(r + 8) * ld + c0);
+                a3 += IO<DT_IN>::load4(x, (size_t)(r + 12) * ld + c0);
+            }
+            for (; r < r1; r += 4) a += IO<DT_IN>::load4(x, (size_t)r * ld + c0);
+            a = (a + a1) + (a2 + a3);
+        } else {
+            for (int64_t r = r0 + w; r < r1; r += 4)
+                for (int u = 0; u < 4 && c0 + u < C; ++u) a[u] += IO<DT_IN>::load1(x, (size_t)r * ld + c0 + u);
+        }
     }
-    for (int u = 0; u < 4 && c0 + u < C; ++u) part[(size_t)blockIdx.y * C + c0 + u] = a[u];
+    red[w][lane] = a;
+    __syncthreads();
+    if (w == 0 && c0 < C) {
+        const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        for (int u = 0; u < 4 && c0 + u < C; ++u) part[(size_t)blockIdx.y * C + c0 + u] = t[u];
+    }
 }
 
+// grid ceil(C/64), 1024 threads = 16 partial-phases x 64 columns; fixed summation order
 template <int DT_OUT>
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int64_t P, int64_t C,
-                                                            void* __restrict__ out, float scale, int accumulate) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f;
-    for (int64_t p = 0; p < P; ++p) a += part[(size_t)p * C + c];
-    a *= scale;
-    if (accumulate) a += IO<DT_OUT>::load1(out, c);
-    IO<DT_OUT>::store1(out, c, a);
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int64_t P, int64_t C,
+                                                             void* __restrict__ out, float scale, int accumulate) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        int64_t p = ph;
+        for (; p + 16 < P; p += 32) {
+            a0 += part[(size_t)p * C + c];
+            a1 += part[(size_t)(p + 16) * C + c];
+        }
+        for (; p < P; p += 16) a0 += part[(size_t)p * C + c];
+    }
+    red[ph][cl] = a0 + a1;
+    __syncthreads();
+    if (ph == 0 && c < C) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += red[q][cl];
+        a *= scale;
+        if (accumulate) a += IO<DT_OUT>::load1(out, c);
+        IO<DT_OUT>::store1(out, c, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -562,9 +596,9 @@ size_t kvq_ln_bwd_workspace_bytes(int64_t N, int H) {
 
 static int colsum_f32_partials(const float* part, int64_t P, int64_t C, void* out, int out_dtype, float scale, int accumulate,
                                hipStream_t st) {
-    dim3 grid((unsigned)((C + 255) / 256));
-    DISPATCH_DT(out_dtype, hipLaunchKernelGGL(colsum_final_kernel<KVQ_F32>, grid, dim3(256), 0, st, part, P, C, out, scale, accumulate),
-                hipLaunchKernelGGL(colsum_final_kernel<KVQ_BF16>, grid, dim3(256), 0, st, part, P, C, out, scale, accumulate));
+    dim3 grid((unsigned)((C + 63) / 64));
+    DISPATCH_DT(out_dtype, hipLaunchKernelGGL(colsum_final_kernel<KVQ_F32>, grid, dim3(1024), 0, st, part, P, C, out, scale, accumulate),
+                hipLaunchKernelGGL(colsum_final_kernel<KVQ_BF16>, grid, dim3(1024), 0, st, part, P, C, out, scale, accumulate));
     return check_launch("colsum_final_kernel");
 }
 
@@ -605,7 +639,7 @@ int kvq_colsum(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, vo
     if (!ws || ws_bytes < need) return fail(KVQ_E_WORKSPACE, "kvq_colsum: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     const int64_t P = (N + CS_ROWS - 1) / CS_ROWS;
-    dim3 grid((unsigned)((C + 1023) / 1024), (unsigned)P);
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)P);
     DISPATCH_DT(in_dtype, hipLaunchKernelGGL(colsum_partial_kernel<KVQ_F32>, grid, dim3(256), 0, st, x, N, C, ld, (float*)ws),
                 hipLaunchKernelGGL(colsum_partial_kernel<KVQ_BF16>, grid, dim3(256), 0, st, x, N, C, ld, (float*)ws));
     int rc = check_launch("colsum_partial_kernel");

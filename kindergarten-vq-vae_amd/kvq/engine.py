@@ -205,12 +205,15 @@ class TrainEngine:
         self._pending_hi = self.flat.n
         self._works = []
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
+        self._gen = torch.Generator(device=dev)
 
     # ------------------------------------------------------------------------------------------------------------
     # small helpers
     # ------------------------------------------------------------------------------------------------------------
     def _lr_now(self):
-        k = sum(1 for m in self.milestones if self.step_count >= m)
+        """MultiStepLR ticked once per optimiser step (Trainer.py:114-115): the s-th step (1-based) sees s-1 ticks."""
+        ticks = self.step_count - 1
+        k = sum(1 for m in self.milestones if ticks >= m)
         return self.lr * (self.gamma ** k)
 
     def _site(self):
@@ -251,7 +254,8 @@ class TrainEngine:
         keep = None
         p = cfg.hidden_dropout_prob if training else 0.0
         if p > 0:
-            keep = (torch.rand_like(out, dtype=torch.float32) >= p).to(out.dtype) * (1.0 / (1.0 - p))
+            self._gen.manual_seed(self._step_seed * 64 + self._site())        # reproducible per (step, site), like the Philox sites
+            keep = (torch.rand(out.shape, dtype=torch.float32, device=self.dev, generator=self._gen) >= p).to(out.dtype) * (1.0 / (1.0 - p))
             out = out * keep
         return out, (ids, pre, mean, rstd, keep)
 
