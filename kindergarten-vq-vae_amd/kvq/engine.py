@@ -38,6 +38,35 @@ def _round_up(x, a):
     return (x + a - 1) // a * a
 
 
+_TUNING_LOADED = False
+
+
+def _load_gemm_tuning():
+    """hipBLASLt/rocBLAS solution choices for this step's GEMM shapes, tuned once on an MI355X with PyTorch's TunableOp
+    and shipped in tuning/ (a lookup table of library solution ids; no tuning happens at run time).  Shapes not in the
+    table use the library's default heuristic."""
+    global _TUNING_LOADED
+    if _TUNING_LOADED:
+        return
+    _TUNING_LOADED = True
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuning", "tunableop_gfx950.csv")
+    if os.environ.get("KVQ_GEMM_TUNING", "1") == "0" or not os.path.exists(path):
+        return
+    try:
+        import torch.cuda.tunable as tn
+        tn.enable(True)
+        tn.tuning_enable(os.environ.get("KVQ_GEMM_TUNING") == "tune")
+        if os.environ.get("KVQ_GEMM_TUNING") == "tune":
+            tn.set_filename(os.environ.get("KVQ_GEMM_TUNING_OUT", "gpurun_out/tunableop_new.csv"), False)
+            tn.set_max_tuning_duration(15)
+        else:
+            tn.read_file(path)
+            tn.write_file_on_exit(False)
+    except Exception as e:   # tuning tables are an optimisation only
+        print(f"[kvq] GEMM tuning table not loaded: {e}")
+
+
 class FlatParams:
     """Flat master / shadow / gradient / moment buffers over a list of (name, parameter, padded_numel)."""
 
@@ -205,6 +234,7 @@ class TrainEngine:
         self._pending_hi = self.flat.n
         self._works = []
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
+        _load_gemm_tuning()
         self._gen = torch.Generator(device=dev)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -225,6 +255,21 @@ class TrainEngine:
         b = self.flat.fused(fused[1], self.flat.shadow) if fused else self.flat.w(bname)
         return torch.addmm(b, x, W.t())
 
+    # split-K factors for the weight-gradient GEMMs gW[M,N] = gy[Ntok,M]^T x[Ntok,N]: the contraction (Ntok = 8192) is long
+    # and the output small, so a single GEMM leaves most CUs idle; S batched slices + one sum fill the chip
+    # (measured with tools/gemm_probe.py on MI355X, hipBLASLt 1.0: 1.3-1.8x over the plain call)
+    _SPLITS = {(768, 768): 16, (2304, 768): 8, (3072, 768): 4, (768, 3072): 4, (1536, 768): 8}
+
+    def _wgrad(self, gy, x, out):
+        Ntok, M = gy.shape
+        N = x.shape[1]
+        S = self._SPLITS.get((M, N), 0) if self.dtype == torch.bfloat16 else 0
+        if S and Ntok % S == 0 and Ntok // S >= 256 and gy.is_contiguous() and x.is_contiguous():
+            part = torch.bmm(gy.view(S, Ntok // S, M).transpose(1, 2), x.view(S, Ntok // S, N))
+            torch.sum(part, 0, out=out)
+        else:
+            torch.mm(gy.t(), x, out=out)
+
     def _linear_bwd(self, gy, x, wnames, bnames, need_gx=True, gx_accum=None):
         """Weight / bias gradients straight into the flat gradient buffer; returns gx (or accumulates into gx_accum)."""
         fl = self.flat
@@ -233,7 +278,7 @@ class TrainEngine:
         else:
             W, gW, gb = fl.fused(wnames, fl.shadow), fl.fused(wnames, fl.grad), fl.fused(bnames, fl.grad)
         if fl.trainable[wnames[0]]:
-            torch.mm(gy.t(), x, out=gW)
+            self._wgrad(gy, x, gW)
         if fl.trainable[bnames[0]]:
             nnops.colsum(gy, gb)
         if gx_accum is not None:
@@ -464,7 +509,10 @@ class TrainEngine:
         if tr["head.bias"]:
             nnops.colsum(g_logits, fl.g("head.bias", rows=self.Vp))
         if tr["dec.emb.word"]:
-            torch.mm(g_logits.t(), hN, out=fl.g("dec.emb.word", rows=self.Vp))
+            # [Vp,H] = g_logits^T hN is faster computed as its transpose (H rows x Vp columns) and flipped once
+            gWt = torch.mm(hN.t(), g_logits)
+            fl.g("dec.emb.word", rows=self.Vp).copy_(gWt.t())
+            del gWt
         g_hN = torch.mm(g_logits, Wv)
         del logits, g_logits
         g_ta, _ = nnops.ln_bwd(g_hN, hpre, hmean, hrstd, fl.w32("head.ln.w"),
