@@ -114,6 +114,8 @@ int kvq_vq_uses_mfma(int64_t N, int K, int D);
  *   2 (default) = 2-D tiled distance kernel (32 tokens x 128 codes per workgroup, 4 workgroups per CU, 64-bit
  *                 atomicMin hand-over) + streaming epilogue kernel;   1 = single fused kernel (32 tokens x all codes). */
 int kvq_vq_set_forward_variant(int variant);
+/* Diagnostics: resident workgroups per CU the runtime reports for the two forward kernels at their LDS sizes. */
+int kvq_vq_debug_occupancy(int* blocks_per_cu_tiled, int* blocks_per_cu_fused);
 
 /* EMA codebook update (extension named by BASELINE.json north_star; NOT in the reference -> default off):
  *   n_k <- g*n_k + (1-g)*count_k ;  m_k <- g*m_k + (1-g)*sum_{idx_n=k} z_n ;

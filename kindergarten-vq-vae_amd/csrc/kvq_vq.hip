@@ -818,6 +818,20 @@ size_t kvq_vq_workspace_bytes(int64_t N, int K, int D, int G) {
 
 int kvq_vq_uses_mfma(int64_t N, int K, int D) { return mfma_ok(N, K, D) ? 1 : 0; }
 
+int kvq_vq_debug_occupancy(int* blocks_per_cu_tiled, int* blocks_per_cu_fused) {
+    int a = -1, b = -1;
+    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&vq_dist_tile_kernel<KVQ_BF16>),
+                                                                 T2_THREADS, T2_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_fwd_mfma_kernel<KVQ_BF16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&vq_fwd_mfma_kernel<KVQ_BF16>),
+                                                                 NTHREADS, LDS_BYTES);
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(KVQ_E_LAUNCH, "occupancy query failed");
+    if (blocks_per_cu_tiled) *blocks_per_cu_tiled = a;
+    if (blocks_per_cu_fused) *blocks_per_cu_fused = b;
+    return KVQ_OK;
+}
+
 int kvq_vq_set_forward_variant(int variant) {
     if (variant != 1 && variant != 2) return fail(KVQ_E_INVALID, "kvq_vq_set_forward_variant: 1 or 2, got %d", variant);
     g_fwd_variant = variant;

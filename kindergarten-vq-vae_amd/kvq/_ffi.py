@@ -24,6 +24,7 @@ SIGNATURES = {
     "kvq_prof_read": (_int, [C.POINTER(C.c_float), _int]),
     "kvq_vq_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "kvq_vq_set_forward_variant": (_int, [_int]),
+    "kvq_vq_debug_occupancy": (_int, [C.POINTER(_int), C.POINTER(_int)]),
     "kvq_vq_uses_mfma": (_int, [_i64, _int, _int]),
     "kvq_vq_forward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kvq_vq_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _sz, _vp]),

@@ -62,7 +62,8 @@ def _load_gemm_tuning():
             tn.set_max_tuning_duration(15)
         else:
             tn.read_file(path)
-            tn.write_file_on_exit(False)
+            if hasattr(tn, "write_file_on_exit"):
+                tn.write_file_on_exit(False)
     except Exception as e:   # tuning tables are an optimisation only
         print(f"[kvq] GEMM tuning table not loaded: {e}")
 

@@ -1,0 +1,86 @@
+"""Multi-process data parallelism on CPU (gloo, world_size 2): kvq.ddp.GradSync must reproduce the single-process
+gradient of the concatenated batch, with bucketing and the zero_grad/backward/finish protocol of the trainers."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(),
+                               torch.nn.Linear(64, 8))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from kvq import ddp
+    r, _, w = ddp.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    model = _model()
+    if rank == 1:                                    # diverge on purpose: broadcast must repair it
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    ddp.broadcast_parameters(model)
+    model[2].bias.requires_grad_(False)              # a frozen parameter must not break the buckets
+    sync = ddp.GradSync(model.parameters(), bucket_mib=0)      # bucket_mib=0 -> one bucket per parameter (max bucket count)
+    assert len(sync.buckets) == 5
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 16, generator=g); y = torch.randn(8, 8, generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.1)
+    for _ in range(2):
+        sync.zero_grad()
+        torch.nn.functional.mse_loss(model(xs), ys).backward()
+        sync.finish()
+        opt.step()
+    t = torch.tensor([1.0 + rank])
+    ddp.all_reduce_mean_(t)
+    assert t.item() == 1.5
+    if rank == 0:
+        torch.save({k: v.clone() for k, v in model.state_dict().items()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_matches_single_process_big_batch(tmp_path):
+    out = str(tmp_path / "ddp.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    model = _model()
+    model[2].bias.requires_grad_(False)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 16, generator=g); y = torch.randn(8, 8, generator=g)
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.1)
+    for _ in range(2):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(model(x), y).backward()      # mean over the global batch == mean of the two rank means
+        opt.step()
+    for k, v in model.state_dict().items():
+        torch.testing.assert_close(got[k], v, rtol=1e-5, atol=1e-6)
+
+
+def test_gradsync_single_process_is_a_noop_wrapper():
+    from kvq import ddp
+    model = _model()
+    sync = ddp.GradSync(model.parameters(), bucket_mib=1)
+    assert sync.world == 1 and len(sync.buckets) == 1 and sync.grad_bytes() == sum(p.numel() * 4 for p in model.parameters())
+    sync.zero_grad()
+    model(torch.randn(2, 16)).sum().backward()
+    sync.finish()
+    for p in model.parameters():
+        assert p.grad is not None and p.grad.data_ptr() >= sync.buckets[0].flat.data_ptr()
