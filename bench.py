@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--model", default="bert-base-uncased")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--bucket-mib", type=int, default=64)
     ap.add_argument("--path", default="engine", choices=["engine", "autograd"],
                     help="engine = kvq.engine.TrainEngine (explicit fwd/bwd over flat buffers); autograd = kvq.bert + torch autograd")
@@ -180,12 +180,13 @@ def main():
             if cfg is None:
                 from models.bagon.Bagon import LOCAL_BERT_CONFIGS
                 cfg = dict(LOCAL_BERT_CONFIGS[a.model])
-            cores = os.cpu_count() or 1
+            cores = step_oracle.host_cores()
+            print(f"[bench] timing the CPU restatement on {cores} host cores ...", file=sys.stderr, flush=True)
             r = step_oracle.time_cpu_steps(cfg, batch=8, seq_len=a.seq_len, n_e=a.codes, e_dim=D, beta=0.25,
-                                           vocab_size=model.decoder.config.vocab_size, warmup=1, steps=a.cpu_steps,
-                                           threads=cores)
+                                           vocab_size=model.decoder.config.vocab_size, warmup=2, steps=a.cpu_steps,
+                                           threads=cores, log=lambda m: print(m, file=sys.stderr, flush=True))
             out["cpu_baseline"] = {"value": r["sentences_per_s"], "unit": "sentences/s", "cores": r["threads"], "kind": "port",
-                                   "sample": f"{a.cpu_steps} timed steps (median) of oracle/step_oracle.py at batch=8 seq_len={a.seq_len} "
+                                   "sample": f"{r['steps']} timed steps (median) of oracle/step_oracle.py at batch=8 seq_len={a.seq_len} "
                                              f"f32 (BASELINE.json configs[0]), {r['s_per_step']:.2f} s/step"}
         print(json.dumps(out), flush=True)
     if world > 1:

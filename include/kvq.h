@@ -114,6 +114,12 @@ int kvq_vq_uses_mfma(int64_t N, int K, int D);
  *   2 (default) = 2-D tiled distance kernel (32 tokens x 128 codes per workgroup, 4 workgroups per CU, 64-bit
  *                 atomicMin hand-over) + streaming epilogue kernel;   1 = single fused kernel (32 tokens x all codes). */
 int kvq_vq_set_forward_variant(int variant);
+/* Tuning knobs of the tiled distance kernel (results are bit-identical for every setting): kc = contraction floats per LDS
+ * stage (32: 40 KiB LDS, 4 workgroups/CU; 64: 80 KiB, 2 workgroups/CU); prio != 0 raises wave priority around the MFMA cluster;
+ * packed != 0 uses the variant whose codebook operand is pre-packed in MFMA-fragment order and streamed global -> VGPR
+ * (only the token tile goes through LDS): 1 = one 32-token tile per wave, 2 (default) = two tiles per wave sharing each
+ * codebook fragment (64 tokens x 128 codes per workgroup). */
+int kvq_vq_set_tuning(int kc, int prio, int packed);
 /* Diagnostics: resident workgroups per CU the runtime reports for the two forward kernels at their LDS sizes. */
 int kvq_vq_debug_occupancy(int* blocks_per_cu_tiled, int* blocks_per_cu_fused);
 
@@ -166,6 +172,9 @@ int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float*
 size_t kvq_colsum_workspace_bytes(int64_t N, int64_t C);
 int kvq_colsum(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, void* out, int out_dtype, float scale,
                int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* out[i] = sum_s part[s*n + i], f32 accumulate: combines the S split-K slabs of a weight-gradient GEMM.  n %% 4 == 0. */
+int kvq_sum_slabs(const void* part, int S, int64_t n, int io_dtype, void* out, void* stream);
 
 /* BertIntermediate activation (:325-337), erf GELU.  n elements, n %% 4 == 0. */
 int kvq_gelu_fwd(const void* h, void* a, int64_t n, int io_dtype, void* stream);

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
 
 // backward: g_pre = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  g_resid = g_pre;
 //           g_y = g_pre * dropout_mask/(1-p);  dgamma/dbeta partials per workgroup (summed by colsum_final_kernel)
-constexpr int LNB_ROWS = 32;   // rows per workgroup (4 waves x 8 rows)
+constexpr int LNB_ROWS = 8;    // rows per workgroup (4 waves x 2 rows): 1024 workgroups at N = 8192
 
 template <int DT, int PER>
 __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ g_out, const void* __restrict__ pre,
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) { a += lds[(size_t)ww * 2 * H + j]; b += lds[(size_t)ww * 2 * H + H + j]; }
-        part_dgamma[(size_t)blockIdx.x * H + j] = a;
-        part_dbeta[(size_t)blockIdx.x * H + j] = b;
+        part_dgamma[(size_t)blockIdx.x * 2 * H + j] = a;        // partial row layout: [dgamma(H) | dbeta(H)]
+        part_dgamma[(size_t)blockIdx.x * 2 * H + H + j] = b;
     }
 }
 
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restr
 
 // grid ceil(C/64), 1024 threads = 16 partial-phases x 64 columns; fixed summation order
 template <int DT_OUT>
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int64_t P, int64_t C,
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int64_t P, int64_t C, int64_t ldp,
                                                              void* __restrict__ out, float scale, int accumulate) {
     __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
@@ -257,10 +257,10 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
     if (c < C) {
         int64_t p = ph;
         for (; p + 16 < P; p += 32) {
-            a0 += part[(size_t)p * C + c];
-            a1 += part[(size_t)(p + 16) * C + c];
+            a0 += part[(size_t)p * ldp + c];
+            a1 += part[(size_t)(p + 16) * ldp + c];
         }
-        for (; p < P; p += 16) a0 += part[(size_t)p * C + c];
+        for (; p < P; p += 16) a0 += part[(size_t)p * ldp + c];
     }
     red[ph][cl] = a0 + a1;
     __syncthreads();
@@ -271,6 +271,16 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
         a *= scale;
         if (accumulate) a += IO<DT_OUT>::load1(out, c);
         IO<DT_OUT>::store1(out, c, a);
+    }
+}
+
+// out[i] = sum_s part[s*n + i]  (f32 accumulate over S split-K slabs of a weight-gradient GEMM), 8 elements per thread
+template <int DT>
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const void* __restrict__ part, int S, int64_t n4, void* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 a = IO<DT>::load4(part, 4 * i);
+        for (int s2 = 1; s2 < S; ++s2) a += IO<DT>::load4(part, (size_t)s2 * n4 * 4 + 4 * i);
+        IO<DT>::store4(out, 4 * i, a);
     }
 }
 
@@ -367,17 +377,49 @@ struct AttnParams {
     unsigned site;
 };
 
-constexpr int AT_QLD = AT_D + 4;   // padded row stride (floats) of tiles that lanes read row-per-lane
-constexpr int AT_PLD = AT_S + 1;   // padded row stride of the 32x32 probability tiles
+// LDS tiles hold the io dtype (bf16 tiles halve the footprint -> twice the resident waves); arithmetic is f32.
+template <int DT> struct Lds;
+template <> struct Lds<KVQ_F32> { typedef float T; };
+template <> struct Lds<KVQ_BF16> { typedef unsigned short T; };
 
-// lane (row i, half h) copies its 32 elements of one row of a [rows, ld] matrix (head slice) into an LDS tile row
+constexpr int AT_QLD = AT_D + 8;   // padded row stride (elements) of tiles that lanes read row-per-lane (conflict-free)
+constexpr int AT_PLD = AT_S + 1;   // padded row stride of the f32 32x32 probability tiles
+
+// 8 consecutive tile elements -> f32
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const unsigned short* p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+// lane (row i, half h) copies its 32 elements of one row of a [rows, ld] matrix (head slice) into an LDS tile row.
+// `row_off` must address a VALID row (callers clamp the row index); rows that do not exist are zeroed by a select, never by
+// a branch around the loads: hipcc waits vmcnt(0) behind every conditional load, which would serialise the tile fill.
 template <int DT>
-__device__ __forceinline__ void stage_row(const void* base, size_t row_off, bool valid, float* tile_row) {
+__device__ __forceinline__ void stage_row(const void* base, size_t row_off, bool valid, typename Lds<DT>::T* tile_row) {
+    if (DT == KVQ_F32) {
+        f32x4 t[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (valid) t = IO<DT>::load4(base, row_off + 4 * c);
-        *reinterpret_cast<f32x4*>(tile_row + 4 * c) = t;
+        for (int c = 0; c < 8; ++c) t[c] = IO<KVQ_F32>::load4(base, row_off + 4 * c);
+        const float m = valid ? 1.0f : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(tile_row) + 4 * c) = t[c] * m;
+    } else {
+        uint4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + row_off + 8 * c);
+        const unsigned m = valid ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint4 v = {t[c].x & m, t[c].y & m, t[c].z & m, t[c].w & m};
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(tile_row) + 8 * c) = v;
+        }
     }
 }
 
@@ -394,43 +436,54 @@ __device__ __forceinline__ void attn_keep16(const AttnParams& p, int bh, int i, 
 }
 
 // acc[jj] += A[i][:] . B[16h + jj][:]   (A row-per-lane tile with stride AT_QLD, B broadcast tile with stride ldb)
-__device__ __forceinline__ void rows_dot16(const float* Arow, const float* B, int ldb, int h, float (&acc)[16]) {
+template <typename T>
+__device__ __forceinline__ void rows_dot16(const T* Arow, const T* B, int ldb, int h, float (&acc)[16]) {
 #pragma unroll 2
-    for (int d = 0; d < AT_D; d += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(Arow + d);
+    for (int d = 0; d < AT_D; d += 8) {
+        float a[8];
+        ld8(Arow + d, a);
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(B + (16 * h + jj) * ldb + d);
-            acc[jj] = __builtin_fmaf(a.x, bb.x, acc[jj]); acc[jj] = __builtin_fmaf(a.y, bb.y, acc[jj]);
-            acc[jj] = __builtin_fmaf(a.z, bb.z, acc[jj]); acc[jj] = __builtin_fmaf(a.w, bb.w, acc[jj]);
+            float bb[8];
+            ld8(B + (16 * h + jj) * ldb + d, bb);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[jj] = __builtin_fmaf(a[u], bb[u], acc[jj]);
         }
     }
 }
 
-// o[0..31] += sum_j coef[j] * B[j][32h .. 32h+31]   with coef[j] = C[j * cs] (per-lane LDS scalar)
-__device__ __forceinline__ void weighted_rows32(const float* C, int cs, const float* B, int ldb, int h, float (&o)[32]) {
+// o[0..31] += sum_j coef[j] * B[j][32h .. 32h+31]   with coef[j] = C[j * cs] (per-lane f32 LDS scalar)
+template <typename T>
+__device__ __forceinline__ void weighted_rows32(const float* C, int cs, const T* B, int ldb, int h, float (&o)[32]) {
 #pragma unroll 2
     for (int j = 0; j < AT_S; ++j) {
         const float cj = C[j * cs];
-        const float* br = B + j * ldb + 32 * h;
+        const T* br = B + j * ldb + 32 * h;
 #pragma unroll
-        for (int d = 0; d < 32; d += 4) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(br + d);
-            o[d] = __builtin_fmaf(cj, bb.x, o[d]); o[d + 1] = __builtin_fmaf(cj, bb.y, o[d + 1]);
-            o[d + 2] = __builtin_fmaf(cj, bb.z, o[d + 2]); o[d + 3] = __builtin_fmaf(cj, bb.w, o[d + 3]);
+        for (int d = 0; d < 32; d += 8) {
+            float bb[8];
+            ld8(br + d, bb);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[d + u] = __builtin_fmaf(cj, bb[u], o[d + u]);
         }
     }
 }
 
 // scaled + masked scores -> probabilities (before dropout) of query i against keys 16h..16h+15, and the row's lse
 __device__ __forceinline__ void scores_to_probs(const AttnParams& p, int b, int i, int h, bool qvalid, float (&s)[16], float& lse_out) {
+    // key-padding mask as one wave-wide bit mask: lane l < 32 loads mask[b][min(l, Sk-1)] unconditionally, ballot collects
+    unsigned long long kmask = ~0ull;
+    if (p.mask) {                                                   // wave-uniform branch
+        const int l = threadIdx.x & 31;
+        const int64_t mv = p.mask[(size_t)b * p.Sk + (l < p.Sk ? l : p.Sk - 1)];
+        kmask = __ballot(mv != 0);
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const int j = 16 * h + jj;
-        bool ok = j < p.Sk && qvalid;
-        if (ok && p.mask) ok = p.mask[(size_t)b * p.Sk + j] != 0;
-        if (ok && p.causal) ok = j <= i;
+        bool ok = j < p.Sk && qvalid && ((kmask >> j) & 1ull);
+        if (p.causal) ok = ok && j <= i;
         s[jj] = ok ? s[jj] * p.scale : -INFINITY;
         mx = fmaxf(mx, s[jj]);
     }
@@ -449,32 +502,34 @@ __device__ __forceinline__ void scores_to_probs(const AttnParams& p, int b, int 
     lse_out = mref + __logf(fmaxf(sum, 1e-37f));
 }
 
-__device__ __forceinline__ void store32(void* base, size_t off, const float (&o)[32], int dt) {
+template <int DT>
+__device__ __forceinline__ void store32(void* base, size_t off, const float (&o)[32]) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         f32x4 t = {o[4 * c], o[4 * c + 1], o[4 * c + 2], o[4 * c + 3]};
-        if (dt == KVQ_F32) IO<KVQ_F32>::store4(base, off + 4 * c, t);
-        else IO<KVQ_BF16>::store4(base, off + 4 * c, t);
+        IO<DT>::store4(base, off + 4 * c, t);
     }
 }
 
 template <int DT>
 __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float Ks[AT_S * AT_D];
-    __shared__ __attribute__((aligned(16))) float Vs[AT_S * AT_D];
-    __shared__ __attribute__((aligned(16))) float Qs[AT_S * AT_QLD];
+    typedef typename Lds<DT>::T T;
+    __shared__ __attribute__((aligned(16))) T Ks[AT_S * AT_D];
+    __shared__ __attribute__((aligned(16))) T Vs[AT_S * AT_D];
+    __shared__ __attribute__((aligned(16))) T Qs[AT_S * AT_QLD];
     __shared__ float Ps[AT_S * AT_PLD];
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
     const bool kvalid = i < p.Sk, qvalid = i < p.Sq;
-    stage_row<DT>(p.k, ((size_t)b * p.Sk + i) * p.ldk + hd * AT_D + 32 * h, kvalid, Ks + i * AT_D + 32 * h);
-    stage_row<DT>(p.v, ((size_t)b * p.Sk + i) * p.ldv + hd * AT_D + 32 * h, kvalid, Vs + i * AT_D + 32 * h);
-    stage_row<DT>(p.q, ((size_t)b * p.Sq + i) * p.ldq + hd * AT_D + 32 * h, qvalid, Qs + i * AT_QLD + 32 * h);
+    const int ik = kvalid ? i : p.Sk - 1, iq = qvalid ? i : p.Sq - 1;      // clamped rows for the loads
+    stage_row<DT>(p.k, ((size_t)b * p.Sk + ik) * p.ldk + hd * AT_D + 32 * h, kvalid, Ks + i * AT_D + 32 * h);
+    stage_row<DT>(p.v, ((size_t)b * p.Sk + ik) * p.ldv + hd * AT_D + 32 * h, kvalid, Vs + i * AT_D + 32 * h);
+    stage_row<DT>(p.q, ((size_t)b * p.Sq + iq) * p.ldq + hd * AT_D + 32 * h, qvalid, Qs + i * AT_QLD + 32 * h);
     __syncthreads();
     float s[16];
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) s[jj] = 0.f;
-    rows_dot16(Qs + i * AT_QLD, Ks, AT_D, h, s);
+    rows_dot16<T>(Qs + i * AT_QLD, Ks, AT_D, h, s);
     float lse;
     scores_to_probs(p, b, i, h, qvalid, s, lse);
     if (p.p_drop > 0.f) {
@@ -489,36 +544,38 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p) {
     float o[32];
 #pragma unroll
     for (int d = 0; d < 32; ++d) o[d] = 0.f;
-    weighted_rows32(Ps + i * AT_PLD, 1, Vs, AT_D, h, o);      // out[i][32h + d] = sum_j P[i][j] V[j][32h + d]
+    weighted_rows32<T>(Ps + i * AT_PLD, 1, Vs, AT_D, h, o);      // out[i][32h + d] = sum_j P[i][j] V[j][32h + d]
     if (qvalid) {
-        store32(p.out, ((size_t)b * p.Sq + i) * p.ldo + hd * AT_D + 32 * h, o, DT);
+        store32<DT>(p.out, ((size_t)b * p.Sq + i) * p.ldo + hd * AT_D + 32 * h, o);
         if (h == 0 && p.lse) p.lse[((size_t)b * p.nh + hd) * p.Sq + i] = lse;
     }
 }
 
 template <int DT>
 __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float Ks[AT_S * AT_D];
-    __shared__ __attribute__((aligned(16))) float Vs[AT_S * AT_D];
-    __shared__ __attribute__((aligned(16))) float Qs[AT_S * AT_QLD];
-    __shared__ __attribute__((aligned(16))) float Gs[AT_S * AT_QLD];
+    typedef typename Lds<DT>::T T;
+    __shared__ __attribute__((aligned(16))) T Ks[AT_S * AT_D];
+    __shared__ __attribute__((aligned(16))) T Vs[AT_S * AT_D];
+    __shared__ __attribute__((aligned(16))) T Qs[AT_S * AT_QLD];
+    __shared__ __attribute__((aligned(16))) T Gs[AT_S * AT_QLD];
     __shared__ float Ps[AT_S * AT_PLD];     // dropped probabilities  P~[i][j]
     __shared__ float Ds[AT_S * AT_PLD];     // dS[i][j] (already times scale)
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
     const bool kvalid = i < p.Sk, qvalid = i < p.Sq;
-    stage_row<DT>(p.k, ((size_t)b * p.Sk + i) * p.ldk + hd * AT_D + 32 * h, kvalid, Ks + i * AT_D + 32 * h);
-    stage_row<DT>(p.v, ((size_t)b * p.Sk + i) * p.ldv + hd * AT_D + 32 * h, kvalid, Vs + i * AT_D + 32 * h);
-    stage_row<DT>(p.q, ((size_t)b * p.Sq + i) * p.ldq + hd * AT_D + 32 * h, qvalid, Qs + i * AT_QLD + 32 * h);
-    stage_row<DT>(p.g_out, ((size_t)b * p.Sq + i) * p.ldo + hd * AT_D + 32 * h, qvalid, Gs + i * AT_QLD + 32 * h);
+    const int ik = kvalid ? i : p.Sk - 1, iq = qvalid ? i : p.Sq - 1;      // clamped rows for the loads
+    stage_row<DT>(p.k, ((size_t)b * p.Sk + ik) * p.ldk + hd * AT_D + 32 * h, kvalid, Ks + i * AT_D + 32 * h);
+    stage_row<DT>(p.v, ((size_t)b * p.Sk + ik) * p.ldv + hd * AT_D + 32 * h, kvalid, Vs + i * AT_D + 32 * h);
+    stage_row<DT>(p.q, ((size_t)b * p.Sq + iq) * p.ldq + hd * AT_D + 32 * h, qvalid, Qs + i * AT_QLD + 32 * h);
+    stage_row<DT>(p.g_out, ((size_t)b * p.Sq + iq) * p.ldo + hd * AT_D + 32 * h, qvalid, Gs + i * AT_QLD + 32 * h);
     __syncthreads();
     float s[16], dp[16];
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) { s[jj] = 0.f; dp[jj] = 0.f; }
-    rows_dot16(Qs + i * AT_QLD, Ks, AT_D, h, s);
+    rows_dot16<T>(Qs + i * AT_QLD, Ks, AT_D, h, s);
     float lse;
     scores_to_probs(p, b, i, h, qvalid, s, lse);
-    rows_dot16(Gs + i * AT_QLD, Vs, AT_D, h, dp);            // dP~[i][j] = dO[i] . V[j]
+    rows_dot16<T>(Gs + i * AT_QLD, Vs, AT_D, h, dp);            // dP~[i][j] = dO[i] . V[j]
     float keep[16];
     if (p.p_drop > 0.f) attn_keep16(p, bh, i, h, keep);
     else {
@@ -543,19 +600,19 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnParams p) {
         float o[32];
 #pragma unroll
         for (int d = 0; d < 32; ++d) o[d] = 0.f;
-        weighted_rows32(Ds + i * AT_PLD, 1, Ks, AT_D, h, o);   // dQ[i][32h+d] = sum_j dS[i][j] K[j][32h+d]
-        if (qvalid) store32(p.g_q, ((size_t)b * p.Sq + i) * p.ldq + hd * AT_D + 32 * h, o, DT);
+        weighted_rows32<T>(Ds + i * AT_PLD, 1, Ks, AT_D, h, o);   // dQ[i][32h+d] = sum_j dS[i][j] K[j][32h+d]
+        if (qvalid) store32<DT>(p.g_q, ((size_t)b * p.Sq + i) * p.ldq + hd * AT_D + 32 * h, o);
     }
     {   // lane = key j (= i): dK[j] = sum_q dS[q][j] Q[q];  dV[j] = sum_q P~[q][j] dO[q]
         float o[32];
 #pragma unroll
         for (int d = 0; d < 32; ++d) o[d] = 0.f;
-        weighted_rows32(Ds + i, AT_PLD, Qs, AT_QLD, h, o);
-        if (kvalid) store32(p.g_k, ((size_t)b * p.Sk + i) * p.ldk + hd * AT_D + 32 * h, o, DT);
+        weighted_rows32<T>(Ds + i, AT_PLD, Qs, AT_QLD, h, o);
+        if (kvalid) store32<DT>(p.g_k, ((size_t)b * p.Sk + i) * p.ldk + hd * AT_D + 32 * h, o);
 #pragma unroll
         for (int d = 0; d < 32; ++d) o[d] = 0.f;
-        weighted_rows32(Ps + i, AT_PLD, Gs, AT_QLD, h, o);
-        if (kvalid) store32(p.g_v, ((size_t)b * p.Sk + i) * p.ldv + hd * AT_D + 32 * h, o, DT);
+        weighted_rows32<T>(Ps + i, AT_PLD, Gs, AT_QLD, h, o);
+        if (kvalid) store32<DT>(p.g_v, ((size_t)b * p.Sk + i) * p.ldv + hd * AT_D + 32 * h, o);
     }
 }
 
@@ -594,11 +651,11 @@ size_t kvq_ln_bwd_workspace_bytes(int64_t N, int H) {
     return (size_t)blocks * H * 2 * sizeof(float);
 }
 
-static int colsum_f32_partials(const float* part, int64_t P, int64_t C, void* out, int out_dtype, float scale, int accumulate,
-                               hipStream_t st) {
+static int colsum_f32_partials(const float* part, int64_t P, int64_t C, int64_t ldp, void* out, int out_dtype, float scale,
+                               int accumulate, hipStream_t st) {
     dim3 grid((unsigned)((C + 63) / 64));
-    DISPATCH_DT(out_dtype, hipLaunchKernelGGL(colsum_final_kernel<KVQ_F32>, grid, dim3(1024), 0, st, part, P, C, out, scale, accumulate),
-                hipLaunchKernelGGL(colsum_final_kernel<KVQ_BF16>, grid, dim3(1024), 0, st, part, P, C, out, scale, accumulate));
+    DISPATCH_DT(out_dtype, hipLaunchKernelGGL(colsum_final_kernel<KVQ_F32>, grid, dim3(1024), 0, st, part, P, C, ldp, out, scale, accumulate),
+                hipLaunchKernelGGL(colsum_final_kernel<KVQ_BF16>, grid, dim3(1024), 0, st, part, P, C, ldp, out, scale, accumulate));
     return check_launch("colsum_final_kernel");
 }
 
@@ -614,7 +671,7 @@ int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float*
     hipStream_t st = (hipStream_t)stream;
     const int64_t blocks = (N + LNB_ROWS - 1) / LNB_ROWS;
     float* pdg = (float*)ws;
-    float* pdb = pdg + (size_t)blocks * H;
+    float* pdb = nullptr;
     const size_t lds = (size_t)4 * 2 * H * sizeof(float);
     const unsigned th = drop_threshold(p_drop);
 #define LAUNCH_LN_BWD(DTV, PERV)                                                                                             \
@@ -625,8 +682,15 @@ int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float*
 #undef LAUNCH_LN_BWD
     int rc = check_launch("drln_bwd_kernel");
     if (rc) return rc;
-    if (g_gamma) { rc = colsum_f32_partials(pdg, blocks, H, g_gamma, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
-    if (g_beta) { rc = colsum_f32_partials(pdb, blocks, H, g_beta, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
+    const size_t esz = param_grad_dtype == KVQ_F32 ? 4 : 2;
+    if (g_gamma && g_beta && (char*)g_beta == (char*)g_gamma + (size_t)H * esz) {
+        // adjacent destinations (the engine's flat layout): one pass over [dgamma | dbeta]
+        rc = colsum_f32_partials(pdg, blocks, 2 * (int64_t)H, 2 * (int64_t)H, g_gamma, param_grad_dtype, 1.0f, accumulate, st);
+        if (rc) return rc;
+    } else {
+        if (g_gamma) { rc = colsum_f32_partials(pdg, blocks, H, 2 * (int64_t)H, g_gamma, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
+        if (g_beta) { rc = colsum_f32_partials(pdg + H, blocks, H, 2 * (int64_t)H, g_beta, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
+    }
     return KVQ_OK;
 }
 
@@ -644,7 +708,17 @@ int kvq_colsum(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, vo
                 hipLaunchKernelGGL(colsum_partial_kernel<KVQ_BF16>, grid, dim3(256), 0, st, x, N, C, ld, (float*)ws));
     int rc = check_launch("colsum_partial_kernel");
     if (rc) return rc;
-    return colsum_f32_partials((const float*)ws, P, C, out, out_dtype, scale, accumulate, st);
+    return colsum_f32_partials((const float*)ws, P, C, C, out, out_dtype, scale, accumulate, st);
+}
+
+int kvq_sum_slabs(const void* part, int S, int64_t n, int io_dtype, void* out, void* stream) {
+    KVQ_REQUIRE(part && out && S >= 1 && n > 0 && n % 4 == 0, "kvq_sum_slabs: bad argument (n %% 4 == 0 required)");
+    const int64_t n4 = n / 4;
+    unsigned blocks = (unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(sum_slabs_kernel<KVQ_F32>, dim3(blocks), dim3(256), 0, st, part, S, n4, out),
+                hipLaunchKernelGGL(sum_slabs_kernel<KVQ_BF16>, dim3(blocks), dim3(256), 0, st, part, S, n4, out));
+    return check_launch("sum_slabs_kernel");
 }
 
 int kvq_gelu_fwd(const void* h, void* a, int64_t n, int io_dtype, void* stream) {

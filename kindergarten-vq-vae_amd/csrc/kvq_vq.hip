@@ -51,6 +51,7 @@ struct FwdParams {
     const float* e2;    // ws [G,K]  (generic path only)
     float* dump;        // optional [N,K] distances (debug hook), G == 1
     unsigned long long* keys;  // ws [G,N]  (v2 path: packed (distance, code) minima)
+    const float* epack;        // ws [G, ceil(K/32)*32, D]  codebook in MFMA-fragment order (v3 path)
     int64_t N;
     int K, D;
 };
@@ -106,9 +107,13 @@ __device__ __forceinline__ void stage_issue(const FwdParams& p, const float* __r
         er[q] = *reinterpret_cast<const f32x4*>(E + (size_t)code * p.D + kc * KC + c * 4);
     }
     const int r = tid >> 4, c = tid & 15;
+    // unconditional load from a clamped row + select: a branch around the load would make hipcc wait vmcnt(0) right
+    // behind it and serialise the whole prefetch with the MFMA cluster
     const int64_t tok = tok0 + r;
-    f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    zr = tok < p.N ? IO<DT>::load4(p.z, zbase + (size_t)tok * p.D + kc * KC + c * 4) : zero;
+    const int64_t tokc = tok < p.N ? tok : p.N - 1;
+    const f32x4 zv = IO<DT>::load4(p.z, zbase + (size_t)tokc * p.D + kc * KC + c * 4);
+    const float m = tok < p.N ? 1.0f : 0.0f;
+    zr = zv * m;
 }
 
 __device__ __forceinline__ void stage_commit(float* sb, int tid, const f32x4 (&er)[E_CHUNKS_PER_THREAD],
@@ -274,12 +279,20 @@ constexpr int T2_TM = 32;
 constexpr int T2_WAVES = 4;
 constexpr int T2_THREADS = T2_WAVES * WAVE;
 constexpr int T2_CN = T2_WAVES * 32;          // 128 codes per workgroup
-constexpr int T2_KC = 32;                     // floats per stage (128-byte rows)
-constexpr int T2_E_TILE = T2_CN * T2_KC;      // 4096 floats
-constexpr int T2_STAGE = (T2_CN + T2_TM) * T2_KC;   // 5120 floats = 20 KiB
-constexpr size_t T2_LDS_BYTES = 2 * T2_STAGE * sizeof(float);   // 40 KiB: four workgroups fill the CU's 160 KiB
-constexpr int T2_E_CHUNKS = (T2_CN * (T2_KC / 4)) / T2_THREADS;  // 4
-static_assert(T2_TM * (T2_KC / 4) == T2_THREADS, "one z chunk per thread per stage");
+
+// stage geometry, parameterised by the contraction depth per stage KC (32 -> 40 KiB LDS, 4 WG/CU; 64 -> 80 KiB, 2 WG/CU)
+template <int KC> struct T2 {
+    static constexpr int CH = KC / 4;                         // 16-byte chunks per row
+    static constexpr int E_TILE = T2_CN * KC;                 // floats
+    static constexpr int STAGE = (T2_CN + T2_TM) * KC;        // floats
+    static constexpr size_t LDS_BYTES = 2 * STAGE * sizeof(float);
+    static constexpr int E_CHUNKS = (T2_CN * CH) / T2_THREADS;
+    static constexpr int Z_CHUNKS = (T2_TM * CH) / T2_THREADS;
+    static constexpr int WGS_PER_CU = KC == 32 ? 4 : 2;
+    // XOR swizzle of the 16-byte chunk index by the row: conflict-free ds_read_b128 for 32 consecutive rows
+    __device__ static __forceinline__ int swz(int r) { return KC == 32 ? ((r >> 1) & 7) : (r & 15); }
+};
+static_assert(T2<32>::Z_CHUNKS == 1 && T2<64>::Z_CHUNKS == 2, "z chunks per thread");
 
 __device__ __forceinline__ unsigned long long pack_key(float d, int code) {
     unsigned u = __float_as_uint(d);
@@ -287,36 +300,48 @@ __device__ __forceinline__ unsigned long long pack_key(float d, int code) {
     return ((unsigned long long)key << 32) | (unsigned)code;
 }
 
-template <int DT>
+template <int DT, int KC>
 __device__ __forceinline__ void t2_issue(const FwdParams& p, const float* __restrict__ E, size_t zbase, int64_t tok0,
-                                         int code0, int kc, int tid, f32x4 (&er)[T2_E_CHUNKS], f32x4& zr) {
+                                         int code0, int kc, int tid, f32x4 (&er)[T2<KC>::E_CHUNKS], f32x4 (&zr)[T2<KC>::Z_CHUNKS]) {
+    constexpr int CH = T2<KC>::CH;
 #pragma unroll
-    for (int q = 0; q < T2_E_CHUNKS; ++q) {
+    for (int q = 0; q < T2<KC>::E_CHUNKS; ++q) {
         const int L = q * T2_THREADS + tid;
-        const int r = L >> 3, c = L & 7;
+        const int r = L / CH, c = L % CH;
         int code = code0 + r;
         code = code < p.K ? code : p.K - 1;
-        er[q] = *reinterpret_cast<const f32x4*>(E + (size_t)code * p.D + kc * T2_KC + c * 4);
+        er[q] = *reinterpret_cast<const f32x4*>(E + (size_t)code * p.D + kc * KC + c * 4);
     }
-    const int r = tid >> 3, c = tid & 7;
-    const int64_t tok = tok0 + r;
-    f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    zr = tok < p.N ? IO<DT>::load4(p.z, zbase + (size_t)tok * p.D + kc * T2_KC + c * 4) : zero;
-}
-
-__device__ __forceinline__ void t2_commit(float* sb, int tid, const f32x4 (&er)[T2_E_CHUNKS], const f32x4& zr) {
 #pragma unroll
-    for (int q = 0; q < T2_E_CHUNKS; ++q) {
+    for (int q = 0; q < T2<KC>::Z_CHUNKS; ++q) {
         const int L = q * T2_THREADS + tid;
-        const int r = L >> 3, c = L & 7;
-        *reinterpret_cast<f32x4*>(sb + r * T2_KC + ((c ^ ((r >> 1) & 7)) << 2)) = er[q];
+        const int r = L / CH, c = L % CH;
+        const int64_t tok = tok0 + r;
+        const int64_t tokc = tok < p.N ? tok : p.N - 1;                  // no branch around the load (see stage_issue)
+        const f32x4 zv = IO<DT>::load4(p.z, zbase + (size_t)tokc * p.D + kc * KC + c * 4);
+        zr[q] = zv * (tok < p.N ? 1.0f : 0.0f);
     }
-    const int r = tid >> 3, c = tid & 7;
-    *reinterpret_cast<f32x4*>(sb + T2_E_TILE + r * T2_KC + ((c ^ ((r >> 1) & 7)) << 2)) = zr;
 }
 
-template <int DT>
-__global__ __launch_bounds__(T2_THREADS, 4) void vq_dist_tile_kernel(FwdParams p) {
+template <int KC>
+__device__ __forceinline__ void t2_commit(float* sb, int tid, const f32x4 (&er)[T2<KC>::E_CHUNKS], const f32x4 (&zr)[T2<KC>::Z_CHUNKS]) {
+    constexpr int CH = T2<KC>::CH;
+#pragma unroll
+    for (int q = 0; q < T2<KC>::E_CHUNKS; ++q) {
+        const int L = q * T2_THREADS + tid;
+        const int r = L / CH, c = L % CH;
+        *reinterpret_cast<f32x4*>(sb + r * KC + ((c ^ T2<KC>::swz(r)) << 2)) = er[q];
+    }
+#pragma unroll
+    for (int q = 0; q < T2<KC>::Z_CHUNKS; ++q) {
+        const int L = q * T2_THREADS + tid;
+        const int r = L / CH, c = L % CH;
+        *reinterpret_cast<f32x4*>(sb + T2<KC>::E_TILE + r * KC + ((c ^ T2<KC>::swz(r)) << 2)) = zr[q];
+    }
+}
+
+template <int DT, int KC, bool PRIO>
+__global__ __launch_bounds__(T2_THREADS, T2<KC>::WGS_PER_CU) void vq_dist_tile_kernel(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
@@ -325,29 +350,31 @@ __global__ __launch_bounds__(T2_THREADS, 4) void vq_dist_tile_kernel(FwdParams p
     const int code0 = blockIdx.y * T2_CN;
     const float* __restrict__ E = p.E + (size_t)g * p.K * p.D;
     const size_t zbase = (size_t)g * p.N * p.D;
-    const int nst = p.D / T2_KC;
+    const int nst = p.D / KC;
+    constexpr int STAGE = T2<KC>::STAGE;
 
-    f32x4 er[T2_E_CHUNKS];
-    f32x4 zr;
-    t2_issue<DT>(p, E, zbase, tok0, code0, 0, tid, er, zr);
-    t2_commit(smem, tid, er, zr);
+    f32x4 er[T2<KC>::E_CHUNKS];
+    f32x4 zr[T2<KC>::Z_CHUNKS];
+    t2_issue<DT, KC>(p, E, zbase, tok0, code0, 0, tid, er, zr);
+    t2_commit<KC>(smem, tid, er, zr);
     __syncthreads();
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float pe = 0.f, pz = 0.f;
-    const int sw = (i >> 1) & 7;
+    const int sw = T2<KC>::swz(i);
 
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
         const bool more = st + 1 < nst;
-        if (more) t2_issue<DT>(p, E, zbase, tok0, code0, st + 1, tid, er, zr);
-        const float* sb = smem + buf * T2_STAGE;
-        const float* erow = sb + (w * 32 + i) * T2_KC;
-        const float* zrow = sb + T2_E_TILE + i * T2_KC;
+        if (more) t2_issue<DT, KC>(p, E, zbase, tok0, code0, st + 1, tid, er, zr);
+        const float* sb = smem + buf * STAGE;
+        const float* erow = sb + (w * 32 + i) * KC;
+        const float* zrow = sb + T2<KC>::E_TILE + i * KC;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int gq = 0; gq < T2_KC / 8; ++gq) {
+        for (int gq = 0; gq < KC / 8; ++gq) {
             const int slot = ((2 * gq + h) ^ sw) << 2;
             const f32x4 a = *reinterpret_cast<const f32x4*>(erow + slot);
             const f32x4 b = *reinterpret_cast<const f32x4*>(zrow + slot);
@@ -360,7 +387,8 @@ __global__ __launch_bounds__(T2_THREADS, 4) void vq_dist_tile_kernel(FwdParams p
             pz = __builtin_fmaf(b.x, b.x, pz); pz = __builtin_fmaf(b.y, b.y, pz);
             pz = __builtin_fmaf(b.z, b.z, pz); pz = __builtin_fmaf(b.w, b.w, pz);
         }
-        if (more) t2_commit(smem + (buf ^ 1) * T2_STAGE, tid, er, zr);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (more) t2_commit<KC>(smem + (buf ^ 1) * STAGE, tid, er, zr);
         __syncthreads();
     }
 
@@ -408,8 +436,212 @@ __global__ __launch_bounds__(T2_THREADS, 4) void vq_dist_tile_kernel(FwdParams p
     }
 }
 
+// ---- v3: codebook pre-packed in MFMA-fragment order -----------------------------------------------------------
+// The A operand (32 codes x 8 contraction floats per MFMA group) belongs to ONE wave, so staging it through LDS buys
+// nothing and costs the LDS write path.  A tiny kernel re-lays E once per call as
+//     Epack[code_block32][k_group8][lane = (code i, half h)][4 floats] = E[32*cb + i][8*g + 4*h .. +3]
+// so that each A fragment is ONE fully coalesced 1-KiB wave load straight into VGPRs (double-buffered in registers).
+// Only the shared 32-token tile still goes through LDS (8 KiB per workgroup).  Same arithmetic, same bits.
+__global__ __launch_bounds__(256) void vq_pack_codebook_kernel(const float* __restrict__ E, int K, int D, float* __restrict__ Epack) {
+    const int g = blockIdx.y;
+    const int G8 = D / 8;
+    const int64_t total = (int64_t)((K + 31) / 32) * G8 * 64;          // float4 slots
+    const float* Eg = E + (size_t)g * K * D;
+    float* Pg = Epack + (size_t)g * ((K + 31) / 32) * 32 * D;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < total; s += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(s & 63);
+        const int64_t t = s >> 6;
+        const int g8 = (int)(t % G8);
+        const int cb = (int)(t / G8);
+        int code = cb * 32 + (lane & 31);
+        code = code < K ? code : K - 1;                                   // padding rows: masked at the argmin
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Eg + (size_t)code * D + 8 * g8 + 4 * (lane >> 5));
+        *reinterpret_cast<f32x4*>(Pg + 4 * s) = v;
+    }
+}
+
+constexpr int T3_KC = 32;                                    // contraction floats per z stage
+
+// 4 consecutive activation elements kept RAW in registers between the global load and the LDS write
+template <int DT> struct ZRaw;
+template <> struct ZRaw<KVQ_F32> {
+    typedef f32x4 T;
+    __device__ static __forceinline__ T load(const void* base, size_t off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off); }
+    __device__ static __forceinline__ f32x4 cvt(T r) { return r; }
+};
+template <> struct ZRaw<KVQ_BF16> {
+    typedef u16x4 T;
+    __device__ static __forceinline__ T load(const void* base, size_t off) { return *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(base) + off); }
+    __device__ static __forceinline__ f32x4 cvt(T r) {
+        f32x4 v = {bf16_to_f32(r.x), bf16_to_f32(r.y), bf16_to_f32(r.z), bf16_to_f32(r.w)};
+        return v;
+    }
+};
+
+// TT = 32-token tiles per wave (1 or 2): with 2 the wave reuses each codebook fragment for two MFMAs (two independent
+// accumulator chains), halving the codebook traffic per flop; the workgroup then covers 64 tokens x 128 codes.
+// NST > 0: the stage count D/32 is a compile-time constant and the stage loop is fully unrolled (no loop back-edge,
+// so the compiler's s_waitcnt vmcnt counts stay exact); NST == 0: run-time loop for any D % 32 == 0.
+template <int DT, bool PRIO, int TT, int NST>
+__global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_kernel(FwdParams p) {
+    constexpr int TMW = 32 * TT;                              // tokens per workgroup
+    constexpr int ZSTAGE = TMW * T3_KC;                       // floats per z stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int g = blockIdx.z;
+    const int64_t tok0 = (int64_t)blockIdx.x * TMW;
+    const int code0 = blockIdx.y * T2_CN;
+    const size_t zbase = (size_t)g * p.N * p.D;
+    const int nst = NST > 0 ? NST : p.D / T3_KC;
+    const int G8 = p.D / 8;
+    const int ncb = (p.K + 31) / 32;
+    int cb = code0 / 32 + w;
+    const bool wave_has_codes = cb < ncb;
+    cb = wave_has_codes ? cb : ncb - 1;
+    const f32x4* __restrict__ Ap = reinterpret_cast<const f32x4*>(p.epack + (size_t)g * ncb * 32 * p.D) + ((size_t)cb * G8) * 64 + lane;
+
+    // z staging: TT 16-byte chunks per thread per stage (rows of 128 B, chunk swizzle (row>>1)&7)
+    typename ZRaw<DT>::T zreg[TT];                             // raw 4 elements (converted only when written to LDS)
+    int zoff[TT];
+    int64_t ztok[TT];
+    float zmul[TT];
+#pragma unroll
+    for (int q = 0; q < TT; ++q) {
+        const int L = q * T2_THREADS + tid;
+        const int r = L >> 3, c = L & 7;
+        zmul[q] = tok0 + r < p.N ? 1.0f : 0.0f;                          // rows past N: clamped load, zeroed value
+        ztok[q] = tok0 + r < p.N ? tok0 + r : p.N - 1;
+        zoff[q] = r * T3_KC + ((c ^ ((r >> 1) & 7)) << 2);
+        zreg[q] = ZRaw<DT>::load(p.z, zbase + (size_t)ztok[q] * p.D + c * 4);
+        *reinterpret_cast<f32x4*>(smem + zoff[q]) = ZRaw<DT>::cvt(zreg[q]) * zmul[q];
+    }
+    const int zc4 = (tid & 7) * 4;
+    // codebook fragments ping-pong between two NAMED register sets (a0 for even stages, a1 for odd ones): with a
+    // single set + copy the compiler's wait-count merging across the loop back-edge stalls the MFMA cluster on the
+    // prefetch it has just issued
+    f32x4 a0[4], a1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a0[q] = Ap[(size_t)q * 64];
+    __syncthreads();
+
+    f32x16 acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float pe = 0.f, pz[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) pz[t] = 0.f;
+    const int sw = (i >> 1) & 7;
+
+#define KVQ_PREFETCH(AREG, STG)                                                                               \
+    {                                                                                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) AREG[q] = Ap[(size_t)(4 * (STG) + q) * 64];              \
+        _Pragma("unroll") for (int q = 0; q < TT; ++q)                                                         \
+            zreg[q] = ZRaw<DT>::load(p.z, zbase + (size_t)ztok[q] * p.D + (STG) * T3_KC + zc4);                \
+    }
+#define KVQ_COMMIT(BUF)                                                                                        \
+    {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0); /* conversion + LDS write stay BEHIND the MFMA cluster */           \
+        _Pragma("unroll") for (int q = 0; q < TT; ++q)                                                         \
+            *reinterpret_cast<f32x4*>(smem + (BUF) * ZSTAGE + zoff[q]) = ZRaw<DT>::cvt(zreg[q]) * zmul[q];     \
+    }
+#define KVQ_CLUSTER(AREG, BUF)                                                                                 \
+    {                                                                                                          \
+        const float* zst = smem + (BUF) * ZSTAGE;                                                              \
+        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                     \
+            const f32x4 a = AREG[gq];                                                                          \
+            const int slot = ((2 * gq + h) ^ sw) << 2;                                                         \
+            f32x4 b[TT];                                                                                       \
+            _Pragma("unroll") for (int t = 0; t < TT; ++t)                                                     \
+                b[t] = *reinterpret_cast<const f32x4*>(zst + (32 * t + i) * T3_KC + slot);                     \
+            _Pragma("unroll") for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0); \
+            _Pragma("unroll") for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0); \
+            _Pragma("unroll") for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0); \
+            _Pragma("unroll") for (int t = 0; t < TT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0); \
+            pe = __builtin_fmaf(a.x, a.x, pe); pe = __builtin_fmaf(a.y, a.y, pe);                             \
+            pe = __builtin_fmaf(a.z, a.z, pe); pe = __builtin_fmaf(a.w, a.w, pe);                             \
+            _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                   \
+                pz[t] = __builtin_fmaf(b[t].x, b[t].x, pz[t]); pz[t] = __builtin_fmaf(b[t].y, b[t].y, pz[t]);  \
+                pz[t] = __builtin_fmaf(b[t].z, b[t].z, pz[t]); pz[t] = __builtin_fmaf(b[t].w, b[t].w, pz[t]);  \
+            }                                                                                                  \
+        }                                                                                                      \
+        if (PRIO) __builtin_amdgcn_s_setprio(0);                                                               \
+    }
+
+#define KVQ_STAGE_PAIR(ST)                                                                                     \
+    {                                                                                                          \
+        const bool more1 = (ST) + 1 < nst;                                                                     \
+        if (more1) KVQ_PREFETCH(a1, (ST) + 1)                                                                  \
+        KVQ_CLUSTER(a0, 0)                                                                                     \
+        if (more1) KVQ_COMMIT(1)                                                                               \
+        __syncthreads();                                                                                       \
+        if (more1) {                                                                                           \
+            const bool more2 = (ST) + 2 < nst;                                                                 \
+            if (more2) KVQ_PREFETCH(a0, (ST) + 2)                                                              \
+            KVQ_CLUSTER(a1, 1)                                                                                 \
+            if (more2) KVQ_COMMIT(0)                                                                           \
+            __syncthreads();                                                                                   \
+        }                                                                                                      \
+    }
+    if (NST > 0) {
+#pragma unroll
+        for (int sp = 0; sp < (NST + 1) / 2; ++sp) KVQ_STAGE_PAIR(2 * sp)
+    } else {
+        for (int st = 0; st < nst; st += 2) KVQ_STAGE_PAIR(st)
+    }
+#undef KVQ_STAGE_PAIR
+#undef KVQ_PREFETCH
+#undef KVQ_COMMIT
+#undef KVQ_CLUSTER
+
+    const float e2v = pe + __shfl_xor(pe, 32, WAVE);
+    const int cbase = code0 + w * 32;
+    float* red_val = smem;                                   // (dead) z stages: [4 waves][TMW] floats + ints
+    int* red_idx = reinterpret_cast<int*>(smem + T2_WAVES * TMW);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const float z2 = pz[t] + __shfl_xor(pz[t], 32, WAVE);
+        float best = INFINITY;
+        int bidx = INT_MAX;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float e2r = __shfl(e2v, cl, WAVE);
+            const float tt = z2 + e2r;
+            const float dd = tt - 2.0f * acc[t][r];
+            const int code = cbase + cl;
+            if (wave_has_codes && code < p.K) {
+                if (p.dump && tok0 + 32 * t + i < p.N) p.dump[(size_t)(tok0 + 32 * t + i) * p.K + code] = dd;
+                if (cand_better(dd, code, best, bidx)) { best = dd; bidx = code; }
+            }
+        }
+        const float ob = __shfl_xor(best, 32, WAVE);
+        const int oi = __shfl_xor(bidx, 32, WAVE);
+        if (cand_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
+        if (lane < 32) {
+            red_val[w * TMW + 32 * t + i] = best;
+            red_idx[w * TMW + 32 * t + i] = bidx;
+        }
+    }
+    __syncthreads();
+    if (tid < TMW && tok0 + tid < p.N) {
+        float b = red_val[tid];
+        int bi = red_idx[tid];
+#pragma unroll
+        for (int ww = 1; ww < T2_WAVES; ++ww) {
+            const float v = red_val[ww * TMW + tid];
+            const int vi = red_idx[ww * TMW + tid];
+            if (cand_better(v, vi, b, bi)) { b = v; bi = vi; }
+        }
+        if (bi != INT_MAX) atomicMin(p.keys + (size_t)g * p.N + tok0 + tid, pack_key(b, bi));
+    }
+}
+
 // epilogue of the v2 path: 64 tokens per workgroup, one wave per token at a time
-constexpr int EP_TOK = 64;
+constexpr int EP_TOK = 16;
 constexpr int EP_THREADS = 256;
 
 template <int DT>
@@ -747,7 +979,7 @@ static int pick_T(int64_t N, int K, int D) {
 static int64_t chunk_of(int64_t N, int T) { return ((N + T - 1) / T + 255) / 256 * 256; }
 
 struct WsLayout {
-    size_t counts, sumsq, e2, keys, slab, slab_cnt, total;
+    size_t counts, sumsq, e2, keys, epack, slab, slab_cnt, total;
 };
 static WsLayout ws_layout(int64_t N, int K, int D, int G) {
     WsLayout l;
@@ -757,14 +989,16 @@ static WsLayout ws_layout(int64_t N, int K, int D, int G) {
     l.sumsq = off;  off = align_up(off + (size_t)G * N * sizeof(double), 256);
     l.e2 = off;     off = align_up(off + (size_t)G * K * sizeof(float) + 16, 256);
     l.keys = off;   off = align_up(off + (size_t)G * N * sizeof(unsigned long long), 256);
+    l.epack = off;  off = align_up(off + (size_t)G * ((K + 31) / 32) * 32 * D * sizeof(float), 256);
     l.slab_cnt = off; off = align_up(off + (size_t)G * T * K * sizeof(int), 256);
     l.slab = off;   off = align_up(off + (size_t)G * T * K * D * sizeof(float), 256);
     l.total = off;
     return l;
 }
 
-static bool mfma_ok(int64_t N, int K, int D) { return N > 0 && K > 0 && D > 0 && D % T2_KC == 0; }
-static int g_fwd_variant = 2;   // 2 = tiled distance kernel + epilogue kernel; 1 = single fused kernel (needs D % 64 == 0)
+static bool mfma_ok(int64_t N, int K, int D) { return N > 0 && K > 0 && D > 0 && D % 32 == 0; }
+static int g_fwd_variant = 2;
+static int g_t2_kc = 32, g_t2_prio = 1, g_t2_packed = 1, g_t2_tt = 2;   // tuning knobs of the tiled kernel (kvq_vq_set_tuning)   // 2 = tiled distance kernel + epilogue kernel; 1 = single fused kernel (needs D % 64 == 0)
 
 template <int DT>
 static int launch_forward(FwdParams p, int G, bool use_mfma, hipStream_t st) {
@@ -772,8 +1006,47 @@ static int launch_forward(FwdParams p, int G, bool use_mfma, hipStream_t st) {
         hipError_t e = hipMemsetAsync(p.keys, 0xff, (size_t)G * p.N * sizeof(unsigned long long), st);
         if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipMemsetAsync(keys): %s", hipGetErrorString(e));
         dim3 grid((unsigned)((p.N + T2_TM - 1) / T2_TM), (unsigned)((p.K + T2_CN - 1) / T2_CN), (unsigned)G);
+        if (g_t2_packed) {
+            const int64_t slots = (int64_t)((p.K + 31) / 32) * (p.D / 8) * 64;
+            unsigned pb = (unsigned)((slots + 255) / 256 > 2048 ? 2048 : (slots + 255) / 256);
+            hipLaunchKernelGGL(vq_pack_codebook_kernel, dim3(pb, (unsigned)G), dim3(256), 0, st, p.E, p.K, p.D, const_cast<float*>(p.epack));
+            const bool prof = prof_begin(st);
+            if (g_t2_tt == 2) {
+                dim3 grid2((unsigned)((p.N + 63) / 64), grid.y, grid.z);
+                const size_t lds = 2 * 64 * T3_KC * sizeof(float);
+                if (p.D == 768) hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 24>), grid2, dim3(T2_THREADS), lds, st, p);
+                else hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 0>), grid2, dim3(T2_THREADS), lds, st, p);
+            } else {
+                const size_t lds = 2 * 32 * T3_KC * sizeof(float);
+                if (p.D == 768) hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 1, 24>), grid, dim3(T2_THREADS), lds, st, p);
+                else hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 1, 0>), grid, dim3(T2_THREADS), lds, st, p);
+            }
+            if (prof) prof_end(st);
+            int rc = check_launch("vq_dist_packed_kernel");
+            if (rc) return rc;
+            dim3 egrid((unsigned)((p.N + EP_TOK - 1) / EP_TOK), (unsigned)G);
+            hipLaunchKernelGGL(vq_epilogue_kernel<DT>, egrid, dim3(EP_THREADS), 0, st, p);
+            return check_launch("vq_epilogue_kernel");
+        }
+        const bool kc64 = g_t2_kc == 64 && p.D % 64 == 0;
+        if (kc64) {
+            static bool attr_done[2][2] = {{false, false}, {false, false}};
+            if (!attr_done[DT][g_t2_prio]) {
+                const void* fn = g_t2_prio ? reinterpret_cast<const void*>(&vq_dist_tile_kernel<DT, 64, true>)
+                                           : reinterpret_cast<const void*>(&vq_dist_tile_kernel<DT, 64, false>);
+                hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2<64>::LDS_BYTES);
+                if (ea != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
+                attr_done[DT][g_t2_prio] = true;
+            }
+        }
         const bool prof = prof_begin(st);
-        hipLaunchKernelGGL(vq_dist_tile_kernel<DT>, grid, dim3(T2_THREADS), T2_LDS_BYTES, st, p);
+        if (kc64) {
+            if (g_t2_prio) hipLaunchKernelGGL((vq_dist_tile_kernel<DT, 64, true>), grid, dim3(T2_THREADS), T2<64>::LDS_BYTES, st, p);
+            else hipLaunchKernelGGL((vq_dist_tile_kernel<DT, 64, false>), grid, dim3(T2_THREADS), T2<64>::LDS_BYTES, st, p);
+        } else {
+            if (g_t2_prio) hipLaunchKernelGGL((vq_dist_tile_kernel<DT, 32, true>), grid, dim3(T2_THREADS), T2<32>::LDS_BYTES, st, p);
+            else hipLaunchKernelGGL((vq_dist_tile_kernel<DT, 32, false>), grid, dim3(T2_THREADS), T2<32>::LDS_BYTES, st, p);
+        }
         if (prof) prof_end(st);
         int rc = check_launch("vq_dist_tile_kernel");
         if (rc) return rc;
@@ -820,8 +1093,8 @@ int kvq_vq_uses_mfma(int64_t N, int K, int D) { return mfma_ok(N, K, D) ? 1 : 0;
 
 int kvq_vq_debug_occupancy(int* blocks_per_cu_tiled, int* blocks_per_cu_fused) {
     int a = -1, b = -1;
-    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&vq_dist_tile_kernel<KVQ_BF16>),
-                                                                 T2_THREADS, T2_LDS_BYTES);
+    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&vq_dist_tile_kernel<KVQ_BF16, 32, false>),
+                                                                 T2_THREADS, T2<32>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_fwd_mfma_kernel<KVQ_BF16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&vq_fwd_mfma_kernel<KVQ_BF16>),
@@ -829,6 +1102,15 @@ int kvq_vq_debug_occupancy(int* blocks_per_cu_tiled, int* blocks_per_cu_fused) {
     if (e1 != hipSuccess || e2 != hipSuccess) return fail(KVQ_E_LAUNCH, "occupancy query failed");
     if (blocks_per_cu_tiled) *blocks_per_cu_tiled = a;
     if (blocks_per_cu_fused) *blocks_per_cu_fused = b;
+    return KVQ_OK;
+}
+
+int kvq_vq_set_tuning(int kc, int prio, int packed) {
+    if (kc != 32 && kc != 64) return fail(KVQ_E_INVALID, "kvq_vq_set_tuning: kc must be 32 or 64");
+    g_t2_kc = kc;
+    g_t2_prio = prio ? 1 : 0;
+    g_t2_packed = packed ? (packed >= 2 ? 2 : 1) : 0;   // packed: 0 = off, 1 = one 32-token tile per wave, 2 = two
+    g_t2_tt = packed >= 2 ? 2 : 1;
     return KVQ_OK;
 }
 
@@ -858,6 +1140,7 @@ int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G
     p.counts = (unsigned*)(w + l.counts);
     p.e2 = (const float*)(w + l.e2);
     p.keys = (unsigned long long*)(w + l.keys);
+    p.epack = (const float*)(w + l.epack);
     p.dump = nullptr;
     p.N = N; p.K = K; p.D = D;
     hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)G * K * sizeof(unsigned), st);
@@ -888,6 +1171,7 @@ int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int 
     p.z = z; p.E = E; p.z_q = zq; p.idx = (int64_t*)ix;
     p.tok_sumsq = (double*)(w + l.sumsq); p.counts = (unsigned*)(w + l.counts); p.e2 = (const float*)(w + l.e2);
     p.keys = (unsigned long long*)(w + l.keys);
+    p.epack = (const float*)(w + l.epack);
     p.dump = d; p.N = N; p.K = K; p.D = D;
     (void)hipMemsetAsync(p.counts, 0, (size_t)K * sizeof(unsigned), st);
     int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, 1, use_mfma != 0, st)

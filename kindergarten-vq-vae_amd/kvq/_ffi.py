@@ -24,6 +24,7 @@ SIGNATURES = {
     "kvq_prof_read": (_int, [C.POINTER(C.c_float), _int]),
     "kvq_vq_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "kvq_vq_set_forward_variant": (_int, [_int]),
+    "kvq_vq_set_tuning": (_int, [_int, _int, _int]),
     "kvq_vq_debug_occupancy": (_int, [C.POINTER(_int), C.POINTER(_int)]),
     "kvq_vq_uses_mfma": (_int, [_i64, _int, _int]),
     "kvq_vq_forward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -39,6 +40,7 @@ SIGNATURES = {
                                            _int, _int, _vp, _sz, _vp]),
     "kvq_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "kvq_colsum": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _int, _f32, _int, _vp, _sz, _vp]),
+    "kvq_sum_slabs": (_int, [_vp, _int, _i64, _int, _vp, _vp]),
     "kvq_gelu_fwd": (_int, [_vp, _vp, _i64, _int, _vp]),
     "kvq_gelu_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "kvq_attn_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32,

@@ -267,7 +267,7 @@ class TrainEngine:
         S = self._SPLITS.get((M, N), 0) if self.dtype == torch.bfloat16 else 0
         if S and Ntok % S == 0 and Ntok // S >= 256 and gy.is_contiguous() and x.is_contiguous():
             part = torch.bmm(gy.view(S, Ntok // S, M).transpose(1, 2), x.view(S, Ntok // S, N))
-            torch.sum(part, 0, out=out)
+            nnops.sum_slabs(part, out)
         else:
             torch.mm(gy.t(), x, out=out)
 

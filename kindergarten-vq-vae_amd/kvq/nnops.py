@@ -53,6 +53,13 @@ def colsum(x, out, scale=1.0, accumulate=False, cols=None):
     return out
 
 
+def sum_slabs(part, out):
+    """out = part.sum(0) for a [S, ...] stack of split-K partial results (f32 accumulate)."""
+    S = part.shape[0]
+    check(lib().kvq_sum_slabs(part.data_ptr(), S, out.numel(), io_dtype_of(part), out.data_ptr(), stream_ptr()), "kvq_sum_slabs")
+    return out
+
+
 def gelu_fwd(h):
     a = torch.empty_like(h)
     check(lib().kvq_gelu_fwd(h.data_ptr(), a.data_ptr(), h.numel(), io_dtype_of(h), stream_ptr()), "kvq_gelu_fwd")

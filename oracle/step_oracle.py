@@ -74,8 +74,28 @@ def step(model, opt, input_ids, attention_mask, vocab_size, w_recon=1.0, w_vq=1.
                 acc=acc, idx=idx, recon_ids=recon_ids)
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (a GPU box hands a
+    container a share of a much larger host; os.cpu_count() would oversubscribe it by an order of magnitude)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def time_cpu_steps(bert_cfg: dict, batch: int, seq_len: int, n_e: int, e_dim: int, beta: float, vocab_size: int,
-                   warmup: int, steps: int, seed: int = 0, threads: int | None = None):
+                   warmup: int, steps: int, seed: int = 0, threads: int | None = None, budget_s: float = 30.0, log=None):
     """CPU baseline for bench.py: sentences/s of the restated step on this host's cores (f32, train mode, Adam on all params)."""
     import os
     import sys
@@ -88,12 +108,18 @@ def time_cpu_steps(bert_cfg: dict, batch: int, seq_len: int, n_e: int, e_dim: in
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     gen = torch.Generator().manual_seed(69)
     times = []
+    t_begin = time.perf_counter()
     for i in range(warmup + steps):
         ids, mask = random_token_batch(batch, seq_len, gen)
         t0 = time.perf_counter()
         step(model, opt, ids, mask, vocab_size)
+        dt = time.perf_counter() - t0
+        if log:
+            log(f"[cpu_baseline] step {i} ({'warm-up' if i < warmup else 'timed'}): {dt:.2f} s on {torch.get_num_threads()} threads")
         if i >= warmup:
-            times.append(time.perf_counter() - t0)
+            times.append(dt)
+        if len(times) >= 2 and time.perf_counter() - t_begin > budget_s:     # bounded sample
+            break
     times.sort()
     med = times[len(times) // 2]
-    return dict(sentences_per_s=batch / med, s_per_step=med, threads=torch.get_num_threads(), steps=steps, batch=batch)
+    return dict(sentences_per_s=batch / med, s_per_step=med, threads=torch.get_num_threads(), steps=len(times), batch=batch)

@@ -92,6 +92,15 @@ def test_colsum(ops, N, C, ld, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sum_slabs(ops, dtype):
+    torch.manual_seed(4)
+    part = torch.randn(16, 768, 768, device="cuda").to(dtype)
+    out = torch.empty(768, 768, device="cuda", dtype=dtype)
+    ops.sum_slabs(part, out)
+    torch.testing.assert_close(out.float(), part.float().sum(0).to(dtype).float(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gelu(ops, dtype):
     torch.manual_seed(0)
     h = (3 * torch.randn(1000, 3072, device="cuda")).to(dtype)

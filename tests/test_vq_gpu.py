@@ -83,13 +83,15 @@ def test_backward_vs_oracle_and_reference(kvq, name):
     assert not got["grad_E"][unused].any()
 
 
-@pytest.fixture(params=[2, 1], ids=["tiled", "fused"])
+@pytest.fixture(params=["packed2", "packed", "tiled", "tiled64", "fused"])
 def variant(request, kvq):
-    """Both MFMA forward structures (include/kvq.h kvq_vq_set_forward_variant) must give identical bits."""
+    """Every MFMA forward structure (include/kvq.h kvq_vq_set_forward_variant / kvq_vq_set_tuning) must give identical bits."""
     lib = kvq._ffi.lib()
-    assert lib.kvq_vq_set_forward_variant(request.param) == 0
+    fv, kc, packed = {"packed2": (2, 32, 2), "packed": (2, 32, 1), "tiled": (2, 32, 0), "tiled64": (2, 64, 0), "fused": (1, 32, 0)}[request.param]
+    assert lib.kvq_vq_set_forward_variant(fv) == 0 and lib.kvq_vq_set_tuning(kc, 1, packed) == 0
     yield request.param
     lib.kvq_vq_set_forward_variant(2)
+    lib.kvq_vq_set_tuning(32, 1, 2)
 
 
 @pytest.mark.parametrize("name", ["c1_sep", "c1_default", "k8192_sep", "demo_default"])
