@@ -190,6 +190,10 @@ int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mas
                  int Sk, int dh, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed,
                  uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v, void* stream);
 
+/* bf16 attention flavour: 1 (default) = packed-dot kernels (v_dot2c_f32_bf16; probabilities / dS enter P.V, dS.K, dS^T.Q,
+ * P^T.dO rounded to bf16), 0 = convert-and-fma kernels (f32 probabilities).  f32 io always uses the f32 kernels. */
+int kvq_attn_set_variant(int use_dot2);
+
 /* torch.optim.Adam step (models/shelgon3/main.py:91: lr, weight_decay (L2, coupled), amsgrad) on flat buffers.
  *   p, m, v [, vmax] f32; g grad_dtype (scaled by grad_scale first); shadow_bf16 (may be NULL) receives bf16(p_new).
  *   step >= 1 is the 1-based step count for bias correction.  n %% 4 == 0. */

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
 
 // backward: g_pre = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  g_resid = g_pre;
 //           g_y = g_pre * dropout_mask/(1-p);  dgamma/dbeta partials per workgroup (summed by colsum_final_kernel)
-constexpr int LNB_ROWS = 8;    // rows per workgroup (4 waves x 2 rows): 1024 workgroups at N = 8192
+constexpr int LNB_ROWS = 16;   // rows per workgroup (4 waves x 2 rows): 1024 workgroups at N = 8192
 
 template <int DT, int PER>
 __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ g_out, const void* __restrict__ pre,
@@ -616,6 +616,239 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 fast path of the attention kernels: same decomposition, but every inner product runs on v_dot2c_f32_bf16
+// (two bf16 MACs per instruction, no conversion), which needs operands PAIRED along the contraction index:
+//   * row-major tiles [row][64] pair along d            -> Q.K^T and dO.V^T      (dot16)
+//   * "pair-interleaved" tiles Xt[row/2][64] hold (X[2r][d], X[2r+1][d]) in one dword -> P.V, dS.K, dS^T.Q, P^T.dO
+//     (the contraction runs over rows); built at staging time with one neighbour-lane exchange.
+// Probabilities / dS enter the row-contractions rounded to bf16 (as in every bf16 flash-attention kernel).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+constexpr int AB_LD = 36;   // dwords per row of the per-lane-row tiles (32 + 4 pad: conflict-free b128 row reads)
+
+// lane (row i, half h) loads its 32 bf16 (16 dwords) of row `row_off`; rows that do not exist come back as zeros
+__device__ __forceinline__ void load_half_row(const void* base, size_t row_off, bool valid, unsigned (&d)[16]) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + row_off);
+    const unsigned m = valid ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint4 t = p[c];
+        d[4 * c] = t.x & m; d[4 * c + 1] = t.y & m; d[4 * c + 2] = t.z & m; d[4 * c + 3] = t.w & m;
+    }
+}
+__device__ __forceinline__ void store_row_major(unsigned* tile, int ld, int i, int h, const unsigned (&d)[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint4 t = {d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]};
+        *reinterpret_cast<uint4*>(tile + i * ld + 16 * h + 4 * c) = t;
+    }
+}
+// Xt[i/2][d] = (X[i & ~1][d] | X[i | 1][d] << 16): even lanes emit d = 32h .. 32h+15, odd lanes d = 32h+16 .. 32h+31
+__device__ __forceinline__ void store_pair_interleaved(unsigned* tile_t, int i, int h, const unsigned (&d)[16]) {
+    const int odd = i & 1;
+    unsigned out[16];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const unsigned mine = odd ? d[8 + c] : d[c];            // the 16 elements of my d-range, my row
+        const unsigned give = odd ? d[c] : d[8 + c];            // the partner's d-range, my row
+        const unsigned got = __shfl_xor(give, 1, WAVE);         // my d-range, partner's row
+        const unsigned ev = odd ? got : mine, od = odd ? mine : got;   // even row / odd row words (2 elements each)
+        out[2 * c] = (ev & 0xffffu) | (od << 16);
+        out[2 * c + 1] = (ev >> 16) | (od & 0xffff0000u);
+    }
+    unsigned* dst = tile_t + (i >> 1) * 64 + 32 * h + 16 * odd;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint4 t = {out[4 * c], out[4 * c + 1], out[4 * c + 2], out[4 * c + 3]};
+        *reinterpret_cast<uint4*>(dst + 4 * c) = t;
+    }
+}
+
+// acc[jj] += A[i][0..63] . B[16h + jj][0..63]: A per-lane rows (stride AB_LD dwords), B broadcast rows (32 dwords)
+__device__ __forceinline__ void dot16_bf16(const unsigned* Arow, const unsigned* B, int h, float (&acc)[16]) {
+#pragma unroll 2
+    for (int c = 0; c < 8; ++c) {
+        const uint4 a = *reinterpret_cast<const uint4*>(Arow + 4 * c);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const uint4 b = *reinterpret_cast<const uint4*>(B + (16 * h + jj) * 32 + 4 * c);
+            acc[jj] = dot2(a.x, b.x, acc[jj]); acc[jj] = dot2(a.y, b.y, acc[jj]);
+            acc[jj] = dot2(a.z, b.z, acc[jj]); acc[jj] = dot2(a.w, b.w, acc[jj]);
+        }
+    }
+}
+// o[d] += sum_r coef(r) * X[r][32h + d], contraction over the 32 rows r, coefficients as 16 packed pairs cp[rp]
+__device__ __forceinline__ void rows32_bf16(const unsigned (&cp)[16], const unsigned* Xt, int h, float (&o)[32]) {
+#pragma unroll 2
+    for (int rp = 0; rp < 16; ++rp) {
+        const unsigned c = cp[rp];
+        const unsigned* xr = Xt + rp * 64 + 32 * h;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint4 x = *reinterpret_cast<const uint4*>(xr + 4 * q);
+            o[4 * q] = dot2(c, x.x, o[4 * q]); o[4 * q + 1] = dot2(c, x.y, o[4 * q + 1]);
+            o[4 * q + 2] = dot2(c, x.z, o[4 * q + 2]); o[4 * q + 3] = dot2(c, x.w, o[4 * q + 3]);
+        }
+    }
+}
+// this lane's 16 values v[jj] (columns 16h + jj) -> the row's 16 packed pairs over all 32 columns (partner half via shuffle)
+__device__ __forceinline__ void row_pairs(const float (&v)[16], int h, unsigned (&cp)[16]) {
+    unsigned mine[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mine[q] = pack_bf16(v[2 * q], v[2 * q + 1]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned oth = __shfl_xor(mine[q], 32, WAVE);
+        cp[q] = h ? oth : mine[q];
+        cp[8 + q] = h ? mine[q] : oth;
+    }
+}
+__device__ __forceinline__ void store32_bf16(void* base, size_t off, const float (&o)[32]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint4 t = {pack_bf16(o[8 * c], o[8 * c + 1]), pack_bf16(o[8 * c + 2], o[8 * c + 3]),
+                   pack_bf16(o[8 * c + 4], o[8 * c + 5]), pack_bf16(o[8 * c + 6], o[8 * c + 7])};
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(base) + off + 8 * c) = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void attn_fwd_bf16_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned Ks[AT_S * 32];      // row-major, pairs along d
+    __shared__ __attribute__((aligned(16))) unsigned Vt[16 * 64];        // pair-interleaved over keys
+    __shared__ __attribute__((aligned(16))) unsigned Qs[AT_S * AB_LD];   // per-lane rows
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+    const bool kvalid = i < p.Sk, qvalid = i < p.Sq;
+    const int ik = kvalid ? i : p.Sk - 1, iq = qvalid ? i : p.Sq - 1;
+    unsigned kd[16], vd[16], qd[16];
+    load_half_row(p.k, ((size_t)b * p.Sk + ik) * p.ldk + hd * AT_D + 32 * h, kvalid, kd);
+    load_half_row(p.v, ((size_t)b * p.Sk + ik) * p.ldv + hd * AT_D + 32 * h, kvalid, vd);
+    load_half_row(p.q, ((size_t)b * p.Sq + iq) * p.ldq + hd * AT_D + 32 * h, qvalid, qd);
+    store_row_major(Ks, 32, i, h, kd);
+    store_pair_interleaved(Vt, i, h, vd);
+    store_row_major(Qs, AB_LD, i, h, qd);
+    __syncthreads();
+    float s[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) s[jj] = 0.f;
+    dot16_bf16(Qs + i * AB_LD, Ks, h, s);
+    float lse;
+    scores_to_probs(p, b, i, h, qvalid, s, lse);
+    if (p.p_drop > 0.f) {
+        float keep[16];
+        attn_keep16(p, bh, i, h, keep);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) s[jj] *= keep[jj];
+    }
+    unsigned cp[16];
+    row_pairs(s, h, cp);
+    float o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    rows32_bf16(cp, Vt, h, o);
+    if (qvalid) {
+        store32_bf16(p.out, ((size_t)b * p.Sq + i) * p.ldo + hd * AT_D + 32 * h, o);
+        if (h == 0 && p.lse) p.lse[((size_t)b * p.nh + hd) * p.Sq + i] = lse;
+    }
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned Ks[AT_S * 32], Vs[AT_S * 32];          // row-major broadcast tiles
+    __shared__ __attribute__((aligned(16))) unsigned Kt[16 * 64], Qt[16 * 64], Gt[16 * 64];  // pair-interleaved over rows
+    __shared__ __attribute__((aligned(16))) unsigned U[2 * AT_S * AB_LD];  // phase 1: Q | dO per-lane rows; phase 2: P~ | dS as f32 [32][33]
+    unsigned* Qs = U;
+    unsigned* Gs = U + AT_S * AB_LD;
+    float* Ps = reinterpret_cast<float*>(U);
+    float* Ds = reinterpret_cast<float*>(U) + AT_S * AT_PLD;
+    static_assert(2 * AT_S * AT_PLD <= 2 * AT_S * AB_LD, "P/dS tiles must fit in the Q/dO staging area");
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+    const bool kvalid = i < p.Sk, qvalid = i < p.Sq;
+    const int ik = kvalid ? i : p.Sk - 1, iq = qvalid ? i : p.Sq - 1;
+    {
+        unsigned t[16];
+        load_half_row(p.k, ((size_t)b * p.Sk + ik) * p.ldk + hd * AT_D + 32 * h, kvalid, t);
+        store_row_major(Ks, 32, i, h, t);
+        store_pair_interleaved(Kt, i, h, t);
+        load_half_row(p.v, ((size_t)b * p.Sk + ik) * p.ldv + hd * AT_D + 32 * h, kvalid, t);
+        store_row_major(Vs, 32, i, h, t);
+        load_half_row(p.q, ((size_t)b * p.Sq + iq) * p.ldq + hd * AT_D + 32 * h, qvalid, t);
+        store_row_major(Qs, AB_LD, i, h, t);
+        store_pair_interleaved(Qt, i, h, t);
+        load_half_row(p.g_out, ((size_t)b * p.Sq + iq) * p.ldo + hd * AT_D + 32 * h, qvalid, t);
+        store_row_major(Gs, AB_LD, i, h, t);
+        store_pair_interleaved(Gt, i, h, t);
+    }
+    __syncthreads();
+    float s[16], dp[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) { s[jj] = 0.f; dp[jj] = 0.f; }
+    dot16_bf16(Qs + i * AB_LD, Ks, h, s);
+    dot16_bf16(Gs + i * AB_LD, Vs, h, dp);                 // dP~[i][j] = dO[i] . V[j]
+    float lse;
+    scores_to_probs(p, b, i, h, qvalid, s, lse);
+    float keep[16];
+    if (p.p_drop > 0.f) attn_keep16(p, bh, i, h, keep);
+    else {
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) keep[jj] = 1.0f;
+    }
+    float delta = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        dp[jj] *= keep[jj];
+        delta += s[jj] * dp[jj];
+    }
+    delta += __shfl_xor(delta, 32, WAVE);
+    float ds[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        ds[jj] = s[jj] * (dp[jj] - delta) * p.scale;
+        s[jj] *= keep[jj];                                  // P~
+    }
+    __syncthreads();                                        // every lane is done reading Q | dO rows: reuse as P~ | dS
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        Ps[i * AT_PLD + 16 * h + jj] = s[jj];
+        Ds[i * AT_PLD + 16 * h + jj] = ds[jj];
+    }
+    {   // dQ[i][32h+d] = sum_j dS[i][j] K[j][32h+d]
+        unsigned cp[16];
+        row_pairs(ds, h, cp);
+        float o[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = 0.f;
+        rows32_bf16(cp, Kt, h, o);
+        if (qvalid) store32_bf16(p.g_q, ((size_t)b * p.Sq + i) * p.ldq + hd * AT_D + 32 * h, o);
+    }
+    __syncthreads();
+    {   // lane = key j (= i): dK[j] = sum_q dS[q][j] Q[q];  dV[j] = sum_q P~[q][j] dO[q]   (contraction over queries)
+        unsigned cp[16];
+        float o[32];
+#pragma unroll
+        for (int qp = 0; qp < 16; ++qp) cp[qp] = pack_bf16(Ds[(2 * qp) * AT_PLD + i], Ds[(2 * qp + 1) * AT_PLD + i]);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = 0.f;
+        rows32_bf16(cp, Qt, h, o);
+        if (kvalid) store32_bf16(p.g_k, ((size_t)b * p.Sk + i) * p.ldk + hd * AT_D + 32 * h, o);
+#pragma unroll
+        for (int qp = 0; qp < 16; ++qp) cp[qp] = pack_bf16(Ps[(2 * qp) * AT_PLD + i], Ps[(2 * qp + 1) * AT_PLD + i]);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = 0.f;
+        rows32_bf16(cp, Gt, h, o);
+        if (kvalid) store32_bf16(p.g_v, ((size_t)b * p.Sk + i) * p.ldv + hd * AT_D + 32 * h, o);
+    }
+}
+
 }  // namespace kvq
 
 using namespace kvq;
@@ -758,6 +991,13 @@ int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void
     return check_launch("adam_kernel");
 }
 
+static int g_attn_dot2 = 1;   // bf16 io: 1 = packed-dot kernels (v_dot2c_f32_bf16), 0 = convert-and-fma kernels
+
+int kvq_attn_set_variant(int use_dot2) {
+    g_attn_dot2 = use_dot2 ? 1 : 0;
+    return KVQ_OK;
+}
+
 static int attn_check(int B, int nh, int Sq, int Sk, int dh, int io_dtype) {
     KVQ_REQUIRE(B > 0 && nh > 0 && Sq > 0 && Sk > 0, "kvq_attn: sizes must be positive");
     KVQ_REQUIRE(Sq <= AT_S && Sk <= AT_S, "kvq_attn: sequence lengths (%d, %d) above the %d-token kernel limit", Sq, Sk, AT_S);
@@ -777,8 +1017,10 @@ int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mas
     p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.causal = causal;
     p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.site = site;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(attn_fwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p),
-                hipLaunchKernelGGL(attn_fwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p));
+    const bool al = (ldq % 8 == 0) && (ldk % 8 == 0) && (ldv % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0);
+    if (io_dtype == KVQ_F32) hipLaunchKernelGGL(attn_fwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else if (al && g_attn_dot2) hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     return check_launch("attn_fwd_kernel");
 }
 
@@ -793,8 +1035,11 @@ int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mas
     p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.causal = causal;
     p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.site = site;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(attn_bwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p),
-                hipLaunchKernelGGL(attn_bwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p));
+    const bool al = (ldq % 8 == 0) && (ldk % 8 == 0) && (ldv % 8 == 0) && (ldo % 8 == 0) &&
+                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)g_out | (uintptr_t)g_q | (uintptr_t)g_k | (uintptr_t)g_v) % 16 == 0);
+    if (io_dtype == KVQ_F32) hipLaunchKernelGGL(attn_bwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else if (al && g_attn_dot2) hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     return check_launch("attn_bwd_kernel");
 }
 
