@@ -156,17 +156,18 @@ int kvq_ce_backward(const void* logits, const int64_t* target, const float* row_
 
 /* BertSelfOutput / BertOutput (:282-293, :340-352):  out = LayerNorm(dropout(y) + resid).
  *   y, resid (may be NULL), out, pre [N,H] io dtype; gamma, beta [H] f32; pre (may be NULL) = dropout(y)+resid as stored;
- *   mean, rstd [N] f32 (may be NULL).  H %% 4 == 0, H <= 4096. */
+ *   mean, rstd [N] f32 (may be NULL).  H %% 4 == 0, H <= 4096 (backward: H <= 3072). */
 int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
                                 float eps, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* pre,
                                 float* mean, float* rstd, void* stream);
 size_t kvq_ln_bwd_workspace_bytes(int64_t N, int H);
 /* g_y = d/dy, g_resid = d/dresid (either may be NULL); g_gamma, g_beta [H] in param_grad_dtype, overwritten or
- * accumulated into (accumulate != 0); either may be NULL. */
+ * accumulated into (accumulate != 0); either may be NULL.  g_bias_prev [H] (may be NULL) receives the column sums of g_y,
+ * i.e. the bias gradient of the dense layer that produced y (BertSelfOutput.dense / BertOutput.dense). */
 int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float* mean, const float* rstd, const float* gamma,
                                 int64_t N, int H, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* g_y,
-                                void* g_resid, void* g_gamma, void* g_beta, int param_grad_dtype, int accumulate, void* ws,
-                                size_t ws_bytes, void* stream);
+                                void* g_resid, void* g_gamma, void* g_beta, void* g_bias_prev, int param_grad_dtype, int accumulate,
+                                void* ws, size_t ws_bytes, void* stream);
 
 /* out[c] (= or +=) scale * sum_n x[n,c]   (bias gradients).  x [N, ld] in_dtype, out [C] out_dtype. */
 size_t kvq_colsum_workspace_bytes(int64_t N, int64_t C);

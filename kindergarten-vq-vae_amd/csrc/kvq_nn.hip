@@ -127,15 +127,15 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
                                                         const float* __restrict__ gamma, int64_t N, int H, float p_drop,
                                                         unsigned thresh, unsigned long long seed, unsigned site,
                                                         void* __restrict__ g_y, void* __restrict__ g_resid,
-                                                        float* __restrict__ part_dgamma, float* __restrict__ part_dbeta) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][2][H]
+                                                        float* __restrict__ part_dgamma, int want_dbias) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][3][H]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nchunk = H >> 2;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    f32x4 dg[PER], db[PER], gm[PER];
+    f32x4 dg[PER], db[PER], dy[PER], gm[PER];     // dy: column sums of g_y = bias gradient of the dense layer in front
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
-        dg[t] = 0.f; db[t] = 0.f;
+        dg[t] = 0.f; db[t] = 0.f; dy[t] = 0.f;
         const int c = lane + WAVE * t;
         f32x4 one = {0.f, 0.f, 0.f, 0.f};
         gm[t] = c < nchunk ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : one;
@@ -178,27 +178,33 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
                         gp.z *= keep_scale(b.z, thresh, inv_keep); gp.w *= keep_scale(b.w, thresh, inv_keep);
                     }
                     IO<DT>::store4(g_y, off, gp);
+                    // what the consumer of g_y reads back is the STORED (possibly bf16-rounded) value
+                    dy[t].x += IO<DT>::round(gp.x); dy[t].y += IO<DT>::round(gp.y);
+                    dy[t].z += IO<DT>::round(gp.z); dy[t].w += IO<DT>::round(gp.w);
                 }
             }
         }
     }
-    float* l_dg = lds + (size_t)w * 2 * H;
+    float* l_dy = lds + (size_t)w * 3 * H;
+    float* l_dg = l_dy + H;
     float* l_db = l_dg + H;
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int c = lane + WAVE * t;
         if (c < nchunk) {
+            *reinterpret_cast<f32x4*>(l_dy + 4 * c) = dy[t];
             *reinterpret_cast<f32x4*>(l_dg + 4 * c) = dg[t];
             *reinterpret_cast<f32x4*>(l_db + 4 * c) = db[t];
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < H; j += 256) {
-        float a = 0.f, b = 0.f;
+    // partial row layout: [dbias_prev(H) | dgamma(H) | dbeta(H)]
+    for (int j = threadIdx.x; j < 3 * H; j += 256) {
+        if (j < H && !want_dbias) continue;
+        float a = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) { a += lds[(size_t)ww * 2 * H + j]; b += lds[(size_t)ww * 2 * H + H + j]; }
-        part_dgamma[(size_t)blockIdx.x * 2 * H + j] = a;        // partial row layout: [dgamma(H) | dbeta(H)]
-        part_dgamma[(size_t)blockIdx.x * 2 * H + H + j] = b;
+        for (int ww = 0; ww < 4; ++ww) a += lds[(size_t)ww * 3 * H + j];
+        part_dgamma[(size_t)blockIdx.x * 3 * H + j] = a;
     }
 }
 
@@ -881,7 +887,7 @@ int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* g
 
 size_t kvq_ln_bwd_workspace_bytes(int64_t N, int H) {
     const int64_t blocks = (N + LNB_ROWS - 1) / LNB_ROWS;
-    return (size_t)blocks * H * 2 * sizeof(float);
+    return (size_t)blocks * H * 3 * sizeof(float);
 }
 
 static int colsum_f32_partials(const float* part, int64_t P, int64_t C, int64_t ldp, void* out, int out_dtype, float scale,
@@ -894,35 +900,45 @@ static int colsum_f32_partials(const float* part, int64_t P, int64_t C, int64_t 
 
 int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float* mean, const float* rstd, const float* gamma,
                                 int64_t N, int H, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* g_y,
-                                void* g_resid, void* g_gamma, void* g_beta, int param_grad_dtype, int accumulate, void* ws,
-                                size_t ws_bytes, void* stream) {
+                                void* g_resid, void* g_gamma, void* g_beta, void* g_bias_prev, int param_grad_dtype, int accumulate,
+                                void* ws, size_t ws_bytes, void* stream) {
     KVQ_REQUIRE(g_out && pre && mean && rstd && gamma && N > 0 && H > 0, "kvq_dropout_residual_ln_bwd: bad argument");
-    KVQ_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAX_PER_LANE, "kvq_dropout_residual_ln_bwd: H=%d unsupported", H);
+    KVQ_REQUIRE(H % 4 == 0 && H <= 3072, "kvq_dropout_residual_ln_bwd: H=%d unsupported (multiple of 4, <= 3072: 48*H bytes of LDS)", H);
     KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
     const size_t need = kvq_ln_bwd_workspace_bytes(N, H);
     if (!ws || ws_bytes < need) return fail(KVQ_E_WORKSPACE, "kvq_dropout_residual_ln_bwd: workspace %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     const int64_t blocks = (N + LNB_ROWS - 1) / LNB_ROWS;
+    KVQ_REQUIRE(!g_bias_prev || g_y, "kvq_dropout_residual_ln_bwd: g_bias_prev needs g_y");
     float* pdg = (float*)ws;
-    float* pdb = nullptr;
-    const size_t lds = (size_t)4 * 2 * H * sizeof(float);
+    const int want_dbias = g_bias_prev ? 1 : 0;
+    const size_t lds = (size_t)4 * 3 * H * sizeof(float);
     const unsigned th = drop_threshold(p_drop);
 #define LAUNCH_LN_BWD(DTV, PERV)                                                                                             \
     hipLaunchKernelGGL((drln_bwd_kernel<DTV, PERV>), dim3((unsigned)blocks), dim3(256), lds, st, g_out, pre, mean, rstd, gamma, \
-                       N, H, p_drop, th, (unsigned long long)seed, site, g_y, g_resid, pdg, pdb)
+                       N, H, p_drop, th, (unsigned long long)seed, site, g_y, g_resid, pdg, want_dbias)
     if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 4), LAUNCH_LN_BWD(KVQ_BF16, 4)); }
     else { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 16), LAUNCH_LN_BWD(KVQ_BF16, 16)); }
 #undef LAUNCH_LN_BWD
     int rc = check_launch("drln_bwd_kernel");
     if (rc) return rc;
     const size_t esz = param_grad_dtype == KVQ_F32 ? 4 : 2;
-    if (g_gamma && g_beta && (char*)g_beta == (char*)g_gamma + (size_t)H * esz) {
-        // adjacent destinations (the engine's flat layout): one pass over [dgamma | dbeta]
-        rc = colsum_f32_partials(pdg, blocks, 2 * (int64_t)H, 2 * (int64_t)H, g_gamma, param_grad_dtype, 1.0f, accumulate, st);
+    const int64_t H3 = 3 * (int64_t)H;
+    const bool gb_adj = g_gamma && g_beta && (char*)g_beta == (char*)g_gamma + (size_t)H * esz;
+    const bool all_adj = gb_adj && g_bias_prev && (char*)g_gamma == (char*)g_bias_prev + (size_t)H * esz;
+    if (all_adj) {
+        // [dense bias | LN weight | LN bias] are adjacent in the engine's flat layout: ONE pass writes all three
+        rc = colsum_f32_partials(pdg, blocks, H3, H3, g_bias_prev, param_grad_dtype, 1.0f, accumulate, st);
         if (rc) return rc;
     } else {
-        if (g_gamma) { rc = colsum_f32_partials(pdg, blocks, H, 2 * (int64_t)H, g_gamma, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
-        if (g_beta) { rc = colsum_f32_partials(pdg + H, blocks, H, 2 * (int64_t)H, g_beta, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
+        if (g_bias_prev) { rc = colsum_f32_partials(pdg, blocks, H, H3, g_bias_prev, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
+        if (gb_adj) {
+            rc = colsum_f32_partials(pdg + H, blocks, 2 * (int64_t)H, H3, g_gamma, param_grad_dtype, 1.0f, accumulate, st);
+            if (rc) return rc;
+        } else {
+            if (g_gamma) { rc = colsum_f32_partials(pdg + H, blocks, H, H3, g_gamma, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
+            if (g_beta) { rc = colsum_f32_partials(pdg + 2 * H, blocks, H, H3, g_beta, param_grad_dtype, 1.0f, accumulate, st); if (rc) return rc; }
+        }
     }
     return KVQ_OK;
 }

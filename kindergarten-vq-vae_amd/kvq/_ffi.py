@@ -36,7 +36,7 @@ SIGNATURES = {
     "kvq_ce_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp]),
     "kvq_dropout_residual_ln_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp]),
     "kvq_ln_bwd_workspace_bytes": (_sz, [_i64, _int]),
-    "kvq_dropout_residual_ln_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp,
+    "kvq_dropout_residual_ln_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp,
                                            _int, _int, _vp, _sz, _vp]),
     "kvq_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "kvq_colsum": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _int, _f32, _int, _vp, _sz, _vp]),

@@ -271,7 +271,7 @@ class TrainEngine:
         else:
             torch.mm(gy.t(), x, out=out)
 
-    def _linear_bwd(self, gy, x, wnames, bnames, need_gx=True, gx_accum=None):
+    def _linear_bwd(self, gy, x, wnames, bnames, need_gx=True, gx_accum=None, bias_done=False):
         """Weight / bias gradients straight into the flat gradient buffer; returns gx (or accumulates into gx_accum)."""
         fl = self.flat
         if len(wnames) == 1:
@@ -280,7 +280,7 @@ class TrainEngine:
             W, gW, gb = fl.fused(wnames, fl.shadow), fl.fused(wnames, fl.grad), fl.fused(bnames, fl.grad)
         if fl.trainable[wnames[0]]:
             self._wgrad(gy, x, gW)
-        if fl.trainable[bnames[0]]:
+        if fl.trainable[bnames[0]] and not bias_done:     # bias_done: the LayerNorm backward kernel already produced it
             nnops.colsum(gy, gb)
         if gx_accum is not None:
             gx_accum.addmm_(gy, W)
@@ -360,8 +360,9 @@ class TrainEngine:
         tr = fl.trainable
         g_ao, g_x = nnops.ln_bwd(g_out, lnpre, mean, rstd, fl.w32(pre + "ln.w"), p_hid, self._step_seed, site_o,
                                  g_gamma=fl.g(pre + "ln.w") if tr[pre + "ln.w"] else None,
-                                 g_beta=fl.g(pre + "ln.b") if tr[pre + "ln.b"] else None)
-        g_ctx = self._linear_bwd(g_ao, ctx, [pre + "o.w"], [pre + "o.b"])
+                                 g_beta=fl.g(pre + "ln.b") if tr[pre + "ln.b"] else None,
+                                 g_bias_prev=fl.g(pre + "o.b") if tr[pre + "o.b"] else None)
+        g_ctx = self._linear_bwd(g_ao, ctx, [pre + "o.w"], [pre + "o.b"], bias_done=True)
         g_qkv = torch.empty_like(qkv)
         if kv_src is None:
             q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
@@ -393,8 +394,9 @@ class TrainEngine:
         tr = fl.trainable
         g_f, g_x = nnops.ln_bwd(g_out, lnpre, mean, rstd, fl.w32(pre + "ln2.w"), p_hid, self._step_seed, site,
                                 g_gamma=fl.g(pre + "ln2.w") if tr[pre + "ln2.w"] else None,
-                                g_beta=fl.g(pre + "ln2.b") if tr[pre + "ln2.b"] else None)
-        g_a = self._linear_bwd(g_f, a, [pre + "f2.w"], [pre + "f2.b"])
+                                g_beta=fl.g(pre + "ln2.b") if tr[pre + "ln2.b"] else None,
+                                g_bias_prev=fl.g(pre + "f2.b") if tr[pre + "f2.b"] else None)
+        g_a = self._linear_bwd(g_f, a, [pre + "f2.w"], [pre + "f2.b"], bias_done=True)
         g_h = nnops.gelu_bwd(h, g_a, out=g_a)
         self._linear_bwd(g_h, x, [pre + "f1.w"], [pre + "f1.b"], gx_accum=g_x)
         return g_x

@@ -27,17 +27,19 @@ def ln_fwd(y, resid, gamma, beta, eps, p_drop=0.0, seed=0, site=0, save_pre=True
 
 
 def ln_bwd(g_out, pre, mean, rstd, gamma, p_drop=0.0, seed=0, site=0, g_gamma=None, g_beta=None, accumulate=False,
-           need_g_y=True, need_g_resid=True):
-    """Returns (g_y, g_resid).  g_gamma / g_beta (f32 or bf16 [H]) are written (or accumulated into) when given."""
+           need_g_y=True, need_g_resid=True, g_bias_prev=None):
+    """Returns (g_y, g_resid).  g_gamma / g_beta (f32 or bf16 [H]) are written (or accumulated into) when given;
+    g_bias_prev receives colsum(g_y) = the bias gradient of the dense layer in front of this block."""
     N, H = g_out.shape
     g_y = torch.empty_like(g_out) if need_g_y else None
     g_resid = torch.empty_like(g_out) if need_g_resid else None
     l = lib()
     ws = _workspace(g_out.device, l.kvq_ln_bwd_workspace_bytes(N, H))
-    pdt = io_dtype_of(g_gamma) if g_gamma is not None else (io_dtype_of(g_beta) if g_beta is not None else 0)
+    ref = g_gamma if g_gamma is not None else (g_beta if g_beta is not None else g_bias_prev)
+    pdt = io_dtype_of(ref) if ref is not None else 0
     check(l.kvq_dropout_residual_ln_bwd(g_out.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), N, H,
                                         float(p_drop), int(seed), int(site), io_dtype_of(g_out), _p(g_y), _p(g_resid), _p(g_gamma),
-                                        _p(g_beta), pdt, int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()),
+                                        _p(g_beta), _p(g_bias_prev), pdt, int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()),
           "kvq_dropout_residual_ln_bwd")
     return g_y, g_resid
 
