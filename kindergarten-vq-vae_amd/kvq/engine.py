@@ -231,7 +231,7 @@ class TrainEngine:
         # gradient all-reduce chunks (tail first)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
         self._avg_in_comm = self.world > 1 and dist.get_backend(process_group) == "nccl"   # RCCL averages itself; gloo sums
-        self.chunk = bucket_mib * (1 << 20) // self.flat.grad.element_size()
+        self.chunk = max(bucket_mib * (1 << 20) // self.flat.grad.element_size(), 1 << 16)     # elements per all-reduce chunk
         self._pending_hi = self.flat.n
         self._works = []
         self._ones = torch.ones((), dtype=torch.float32, device=dev)

@@ -24,13 +24,17 @@ def vq_forward_backward_available() -> bool:
 _WS = {}
 
 
-def _workspace(dev, nbytes: int) -> torch.Tensor:
-    """Per-device scratch, grown on demand and kept: size everything once, reuse every step (graph-capture safe
-    after the first call at a given shape)."""
-    ws = _WS.get(dev)
+def _workspace(dev, nbytes: int, tag=None) -> torch.Tensor:
+    """Per-device (and per-stream: `tag`) scratch, grown on demand and kept: size everything once, reuse every step
+    (graph-capture safe after the first call at a given shape).  Kernels that run concurrently on different streams must
+    not share a scratch buffer, hence the stream tag."""
+    if tag is None:
+        tag = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, tag)
+    ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
-        _WS[dev] = ws
+        _WS[key] = ws
     return ws
 
 

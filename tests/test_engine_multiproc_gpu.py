@@ -1,0 +1,82 @@
+"""Two data-parallel ranks of the TrainEngine (both on cuda:0, gloo process group so one GPU suffices) must end up with
+the weights of a single process that trained on the concatenated batch: checks the tail-chunk gradient exchange,
+its stream ordering and the codebook-gradient all-reduce.  (On a multi-GPU node the same code runs over RCCL.)"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build():
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    from models.shelgon3.Shelgon import Shelgon
+    from models.shelgon3.VectorQuantizer import VectorQuantizer
+    torch.manual_seed(0)
+    vq = VectorQuantizer(32, 128, 0.25, vq_codebook_init_values=torch.randn(32, 128))
+    vq.materialize_min_encodings = False
+    return Shelgon("kvq-bert-tiny", vq, "kvq-bert-tiny", None, compute_dtype=torch.float32).cuda().eval()
+
+
+def _data():
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1000, 2000, (8, 16), generator=g)
+    lens = torch.randint(3, 17, (8,), generator=g)
+    ids = ids * (torch.arange(16)[None] < lens[:, None])
+    return ids.cuda(), (ids != 0).long().cuda()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    import torch.distributed as dist
+    from kvq import ddp
+    from kvq.engine import TrainEngine
+    torch.cuda.set_device(0)
+    ddp.init_distributed("gloo")
+    model = _build()
+    ddp.broadcast_parameters(model)
+    eng = TrainEngine(model, lr=1e-3, bucket_mib=0)           # bucket_mib=0 -> 1-element... clamp inside: many small chunks
+    assert eng.world == 2
+    ids, mask = _data()
+    half = slice(rank * 4, rank * 4 + 4)
+    for _ in range(2):
+        eng.train_step(ids[half], mask[half])
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process_big_batch(tmp_path):
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    from kvq.engine import TrainEngine
+    model = _build()
+    eng = TrainEngine(model, lr=1e-3)
+    ids, mask = _data()
+    # the two half-batches have equal token counts, so the mean of the rank means is the global mean
+    for _ in range(2):
+        eng.train_step(ids, mask)
+    ref = model.state_dict()
+    bad = []
+    for k, v in ref.items():
+        if "pooler" in k or "key.bias" in k or "position_ids" in k:
+            continue
+        if not torch.allclose(got[k], v.cpu(), rtol=2e-3, atol=3e-5):
+            bad.append((k, (got[k] - v.cpu()).abs().max().item()))
+    assert not bad, bad[:5]
