@@ -8,7 +8,7 @@ configs[1]: bf16, seq_len 32, per-GPU batch 256, `full` mode (all 247.8 M parame
 Weak scaling: per-GPU batch is fixed, global batch = 256*N.
 
 Extra objects on the line:
-  roofline     the VQ distance+argmin kernel (vq_dist_tile_kernel), timed with HIP events around every launch of the timed
+  roofline     the VQ distance+argmin kernel (vq_dist_packed_kernel), timed with HIP events around every launch of the timed
                region on the stream it runs on; bound = f32 MFMA (exact-f32 distances), HBM figure beside it
   cpu_baseline oracle/step_oracle.py (CPU f32 restatement, "port") timed on this host's cores, rank 0 at N=1 only
 """
@@ -166,7 +166,7 @@ def main():
                        "global_batch": world * a.batch, "seq_len": a.seq_len, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
             "roofline": {
-                "kernel": "vq_dist_tile_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
+                "kernel": "vq_dist_packed_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": (ach_tflops / F32_MFMA_PEAK_TFLOPS) if ach_tflops else None,
                 "traffic": traffic, "avg_launch_us": vq_avg_ms * 1e3 if vq_ms else None, "launches": len(vq_ms),
                 "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
