@@ -571,6 +571,17 @@ class TrainEngine:
             nnops.adam_step(self.E.data.view(-1), self.gE.view(-1), self.mE.view(-1), self.vE.view(-1), self.step_count, lr,
                             b1, b2, self.eps, self.wd, vmax=self.vmaxE.view(-1) if self.vmaxE is not None else None)
 
+    def sync_from_model(self):
+        """Call after the model's parameters were written from outside (load_state_dict, manual init): refreshes the bf16
+        shadow weights the GEMMs read.  (The f32 master buffer IS the parameters' storage, nothing to copy there.)"""
+        self.flat.refresh_shadow()
+
+    @staticmethod
+    def supports(model, seq_len: int) -> bool:
+        """The engine covers BERT-shaped models with 64-wide heads and sentences of at most 32 tokens."""
+        cfg = model.encoder.config
+        return cfg.hidden_size // cfg.num_attention_heads == 64 and seq_len <= 32 and cfg.hidden_size % 32 == 0
+
     def train_step(self, input_ids, attention_mask):
         out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True)
         self.optimizer_step()

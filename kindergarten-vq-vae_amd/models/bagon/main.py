@@ -104,7 +104,11 @@ def main():
              decoded_sentences=decoded, epoch=N_EPOCHS, wandb_run=wandb_run, **common)
     if is_main:
         import pandas as pd
-        pd.DataFrame(decoded).to_feather(f"{run_path}/decoded_sentences.feather")
+        try:
+            pd.DataFrame(decoded).to_feather(f"{run_path}/decoded_sentences.feather")
+        except ImportError as e:          # feather needs pyarrow
+            print(f"[main] feather export unavailable ({e}); writing CSV instead")
+            pd.DataFrame(decoded).to_csv(f"{run_path}/decoded_sentences.csv", index=False)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

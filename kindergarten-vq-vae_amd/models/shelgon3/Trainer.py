@@ -40,8 +40,18 @@ def step(device, model, tokenizer, tokenizer_add_special_tokens: bool, opt,
          loss_recon_rescale_factor: float, loss_recon_weight: float,
          loss_vq_rescale_factor: float, loss_vq_weight: float,
          loss_perp_rescale_factor: float, loss_perp_weight: float,
-         lr_sched, batch, vocab_size: int, stage: str, console=None, max_length: int = 12, grad_sync=None):
+         lr_sched, batch, vocab_size: int, stage: str, console=None, max_length: int = 12, grad_sync=None, engine=None):
     input_ids, attention_mask = tokenize_batch(batch, tokenizer, tokenizer_add_special_tokens, max_length, device)
+
+    if engine is not None:
+        # fast path: kvq.engine.TrainEngine runs forward, backward, gradient exchange and Adam (+ the per-step scheduler
+        # tick) itself; the loss weights were given to its constructor
+        out = engine.train_step(input_ids, attention_mask) if opt is not None else engine.eval_step(input_ids, attention_mask)
+        return {
+            "loss_recon_step": out["loss_recon"].detach(), "loss_vq_step": out["loss_vq"].detach(),
+            "metric_perp_step": out["perplexity"].detach(), "loss_full_step": (out["loss_recon"] + out["loss_vq"]).detach(),
+            "metric_acc_step": out["acc"].detach(), "padding_tokens_pct_step": -69,
+        }, input_ids, out["recon_ids"]
 
     loss_vq_step, metric_perp_step, _indices, loss_recon_step, acc_step, recon_ids = \
         model.forward_loss(input_ids, attention_mask)
@@ -151,7 +161,7 @@ def checkpoint(stats_best: dict, model, checkpoint_dir: str, stage: str):
 
 
 def _run_stage(stage, device, loader, n_batches, model, tokenizer, tokenizer_add_special_tokens, opt, lr_sched, weights,
-               vocab_size, decode_into, epoch, console, max_length, grad_sync, on_batch=None):
+               vocab_size, decode_into, epoch, console, max_length, grad_sync, on_batch=None, engine=None):
     stats_run = init_stats_run()
     n_els_epoch = n_steps = 0
     for batch in islice(loader, n_batches):
@@ -163,7 +173,7 @@ def _run_stage(stage, device, loader, n_batches, model, tokenizer, tokenizer_add
             stats_step, input_ids, recon_ids = step(
                 device=device, model=model, tokenizer=tokenizer, tokenizer_add_special_tokens=tokenizer_add_special_tokens,
                 opt=opt, lr_sched=lr_sched, batch=batch, vocab_size=vocab_size, stage=stage, console=console,
-                max_length=max_length, grad_sync=grad_sync, **weights)
+                max_length=max_length, grad_sync=grad_sync, engine=engine, **weights)
         if decode_into is not None:
             decode_sentences(input_ids, recon_ids, tokenizer, decode_into, epoch, stage, console)
         stats_run = end_of_step_stats_update(stats_run, stats_step, n_els_batch)
@@ -176,7 +186,8 @@ def train(prg, console, device, dl_train, dl_val, n_batches_train: int, n_batche
           tokenizer_add_special_tokens: bool, n_epochs_to_decode_after: int, decoded_sentences: list, opt,
           loss_recon_rescale_factor: float, loss_recon_weight: float, loss_vq_rescale_factor: float, loss_vq_weight: float,
           loss_perp_rescale_factor: float, loss_perp_weight: float, lr_sched, n_epochs: int, vocab_size: int,
-          wandb_run, run_path: str, export_checkpoint: bool, max_length: int = 12, grad_sync=None, is_main: bool = True):
+          wandb_run, run_path: str, export_checkpoint: bool, max_length: int = 12, grad_sync=None, is_main: bool = True,
+          engine=None):
     if not export_checkpoint and console is not None:
         console.print(f"[bold {COLOR_WARNING}]Warning[/bold {COLOR_WARNING}] checkpoint exporting is [bold {COLOR_OFF}]OFF[/bold {COLOR_OFF}]!\n")
     weights = dict(loss_recon_rescale_factor=loss_recon_rescale_factor, loss_recon_weight=loss_recon_weight,
@@ -198,7 +209,8 @@ def train(prg, console, device, dl_train, dl_val, n_batches_train: int, n_batche
         model.train()
         tick = (lambda: (prg.advance(tasks[1], 1), prg.advance(tasks[0], 1 / (n_batches_train + n_batches_val)))) if tasks else None
         run, n_els, n_steps = _run_stage("train", device, dl_train, n_batches_train, model, tokenizer, tokenizer_add_special_tokens,
-                                         opt, lr_sched, weights, vocab_size, decode_now, epoch, console, max_length, grad_sync, tick)
+                                         opt, lr_sched, weights, vocab_size, decode_now, epoch, console, max_length, grad_sync, tick,
+                                         engine=engine)
         stats_train_run, stats_train_best = end_of_epoch_stats_update(run, stats_train_best, n_els, n_steps)
         end_of_epoch_print(stats_train_run, stats_train_best, console, epoch, True, COLOR_TRAIN, STATS_EMOJI_TRAIN, False)
         wandb_run.log(create_wandb_log_dict(epoch, stats_train_run, "train"))
@@ -206,7 +218,8 @@ def train(prg, console, device, dl_train, dl_val, n_batches_train: int, n_batche
         model.eval()
         tick = (lambda: (prg.advance(tasks[2], 1), prg.advance(tasks[0], 1 / (n_batches_train + n_batches_val)))) if tasks else None
         run, n_els, n_steps = _run_stage("val", device, dl_val, n_batches_val, model, tokenizer, tokenizer_add_special_tokens,
-                                         None, None, weights, vocab_size, decode_now, epoch, console, max_length, None, tick)
+                                         None, None, weights, vocab_size, decode_now, epoch, console, max_length, None, tick,
+                                         engine=engine)
         stats_val_run, stats_val_best = end_of_epoch_stats_update(run, stats_val_best, n_els, n_steps)
         end_of_epoch_print(stats_val_run, stats_val_best, console, epoch, False, COLOR_VAL, STATS_EMOJI_VAL, epoch != n_epochs)
         wandb_run.log(create_wandb_log_dict(epoch, stats_val_run, "val"))
@@ -219,7 +232,7 @@ def train(prg, console, device, dl_train, dl_val, n_batches_train: int, n_batche
 def test(prg, console, device, dl_test, n_batches_test, model, tokenizer, tokenizer_add_special_tokens: bool,
          loss_recon_rescale_factor: float, loss_recon_weight: float, loss_vq_rescale_factor: float, loss_vq_weight: float,
          loss_perp_rescale_factor: float, loss_perp_weight: float, decoded_sentences: list, vocab_size: int, epoch: int,
-         wandb_run, max_length: int = 12):
+         wandb_run, max_length: int = 12, engine=None):
     weights = dict(loss_recon_rescale_factor=loss_recon_rescale_factor, loss_recon_weight=loss_recon_weight,
                    loss_vq_rescale_factor=loss_vq_rescale_factor, loss_vq_weight=loss_vq_weight,
                    loss_perp_rescale_factor=loss_perp_rescale_factor, loss_perp_weight=loss_perp_weight)
@@ -227,7 +240,7 @@ def test(prg, console, device, dl_test, n_batches_test, model, tokenizer, tokeni
     model.eval()
     run, n_els, n_steps = _run_stage("test", device, dl_test, n_batches_test, model, tokenizer, tokenizer_add_special_tokens,
                                      None, None, weights, vocab_size, decoded_sentences, epoch, console, max_length, None,
-                                     (lambda: prg.advance(task, 1)) if task is not None else None)
+                                     (lambda: prg.advance(task, 1)) if task is not None else None, engine=engine)
     stats_test_run, stats_test_best = end_of_epoch_stats_update(run, init_stats_best(), n_els, n_steps)
     end_of_epoch_print(stats_test_run, stats_test_best, console, epoch, False, COLOR_TEST, STATS_EMOJI_TEST, True)
     wandb_run.log(create_wandb_log_dict(epoch, stats_test_run, "test"))

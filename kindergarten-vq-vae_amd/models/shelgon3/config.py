@@ -31,6 +31,7 @@ FROM_PRETRAINED_BAGON = None
 CROSS_ATTN_MAKE_TRAINABLE = False
 MODEL_MODE = "full"                  # full | dec-head-ft | enc-head-ft-dec-head-ft | vq-ft
 COMPUTE_DTYPE = "bfloat16"           # bfloat16 | float32
+USE_ENGINE = True                    # kvq.engine.TrainEngine (explicit fwd/bwd on flat buffers) when the model shape allows
 
 VQ_MODE = "VectorQuantizer"
 VQ_N_E = 512

@@ -31,6 +31,7 @@ from common.consts import *  # noqa: E402,F401,F403
 from dsentences.dataset import dSentencesDataset  # noqa: E402
 from dsentences.synthetic import write_corpus  # noqa: E402
 from kvq import ddp  # noqa: E402
+from kvq.engine import TrainEngine  # noqa: E402
 from kvq.runlog import init_run  # noqa: E402
 from kvq.tokenizer import load_tokenizer  # noqa: E402
 from models.shelgon3.Shelgon import Shelgon  # noqa: E402
@@ -84,7 +85,16 @@ def main():
     tokenizer = load_tokenizer(TOKENIZER_NAME)
     opt = Adam(params=[p for p in model.parameters()], lr=LR, weight_decay=WEIGHT_DECAY, amsgrad=AMSGRAD, fused=True)
     lr_sched = MultiStepLR(optimizer=opt, milestones=MILESTONES, gamma=GAMMA) if LR_SCHEDULER == "MultiStepLR" else None
-    grad_sync = ddp.GradSync(model.parameters(), bucket_mib=GRAD_BUCKET_MIB) if world > 1 else None
+    engine = grad_sync = None
+    if USE_ENGINE and TrainEngine.supports(model, TOKENIZED_SENTENCE_MAX_LENGTH):
+        # explicit forward/backward schedule on flat buffers (kvq/engine.py): owns Adam, the scheduler tick and the
+        # RCCL gradient exchange; `opt` above is then only the reference-shaped handle recorded in run_conf.json
+        engine = TrainEngine(model, lr=LR, weight_decay=WEIGHT_DECAY, amsgrad=AMSGRAD,
+                             milestones=MILESTONES if LR_SCHEDULER == "MultiStepLR" else None, gamma=GAMMA,
+                             loss_recon_scale=LOSS_RECON_RESCALE_FACTOR * LOSS_RECON_WEIGHT,
+                             loss_vq_scale=LOSS_VQ_RESCALE_FACTOR * LOSS_VQ_WEIGHT, bucket_mib=GRAD_BUCKET_MIB)
+    elif world > 1:
+        grad_sync = ddp.GradSync(model.parameters(), bucket_mib=GRAD_BUCKET_MIB)
 
     console = prg = None
     if is_main:
@@ -117,20 +127,27 @@ def main():
           n_batches_val=n_batches_val, model=model, tokenizer=tokenizer, tokenizer_add_special_tokens=TOKENIZER_ADD_SPECIAL_TOKENS,
           n_epochs_to_decode_after=N_EPOCHS_TO_DECODE_AFTER, decoded_sentences=decoded_sentences, opt=opt, lr_sched=lr_sched,
           n_epochs=N_EPOCHS, vocab_size=VOCAB_SIZE, wandb_run=wandb_run, run_path=run_path, export_checkpoint=EXPORT_CHECKPOINT,
-          max_length=TOKENIZED_SENTENCE_MAX_LENGTH, grad_sync=grad_sync, is_main=is_main, **weights)
+          max_length=TOKENIZED_SENTENCE_MAX_LENGTH, grad_sync=grad_sync, is_main=is_main, engine=engine, **weights)
 
     best = f"{run_path}/shelgon_ckpt_loss_recon_val_best.pth"
     if EXPORT_CHECKPOINT and is_main and os.path.exists(best):
         model.load_state_dict(torch.load(best, map_location=device)["model_state_dict"])
+        if engine is not None:
+            engine.sync_from_model()
         n_batches_test = int(len(dl_test) * LIM_BATCHES_TEST_PCT)
         test(prg=prg, console=console, device=device, dl_test=dl_test, n_batches_test=n_batches_test, model=model,
              tokenizer=tokenizer, tokenizer_add_special_tokens=TOKENIZER_ADD_SPECIAL_TOKENS, decoded_sentences=decoded_sentences,
-             vocab_size=VOCAB_SIZE, epoch=N_EPOCHS, wandb_run=wandb_run, max_length=TOKENIZED_SENTENCE_MAX_LENGTH, **weights)
+             vocab_size=VOCAB_SIZE, epoch=N_EPOCHS, wandb_run=wandb_run, max_length=TOKENIZED_SENTENCE_MAX_LENGTH, engine=engine,
+             **weights)
     if is_main:
         if prg is not None:
             prg.stop()
         import pandas as pd
-        pd.DataFrame(decoded_sentences).to_feather(f"{run_path}/decoded_sentences.feather")
+        try:
+            pd.DataFrame(decoded_sentences).to_feather(f"{run_path}/decoded_sentences.feather")      # main.py:183-184
+        except ImportError as e:          # feather needs pyarrow
+            print(f"[main] feather export unavailable ({e}); writing CSV instead")
+            pd.DataFrame(decoded_sentences).to_csv(f"{run_path}/decoded_sentences.csv", index=False)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

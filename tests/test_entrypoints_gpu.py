@@ -1,0 +1,69 @@
+"""End-to-end runs of the reference-shaped entry points (models/shelgon3/main.py, models/bagon/main.py) on a tiny
+configuration: dataset synthesis -> split -> loaders -> model -> train (engine / autograd path) -> best-val checkpoint ->
+reload -> test -> artefacts on disk with the reference's names and keys."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "kindergarten-vq-vae_amd")
+
+
+def _run(script, tmp_path, extra):
+    env = dict(os.environ)
+    env.update({
+        "PYTHONPATH": os.pathsep.join([PKG] + ([os.environ["PYTHONPATH"]] if os.environ.get("PYTHONPATH") else [])),
+        "KVQ_SYNTHETIC_SENTENCES": "640", "KVQ_BATCH_SIZE": "32", "KVQ_N_EPOCHS": "2", "KVQ_TOKENIZED_SENTENCE_MAX_LENGTH": "12",
+        "KVQ_ENCODER_MODEL_NAME": "'kvq-bert-tiny'", "KVQ_DECODER_MODEL_NAME": "'kvq-bert-tiny'", "KVQ_LR": "1e-3",
+        "KVQ_RUNS_DIR": repr(str(tmp_path / "runs")),
+    })
+    data = str(tmp_path / "data")
+    env.update(extra(data))
+    r = subprocess.run([sys.executable, os.path.join(PKG, script)], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    runs = glob.glob(str(tmp_path / "runs" / "*"))
+    assert len(runs) == 1
+    return runs[0]
+
+
+@pytest.mark.parametrize("use_engine", [True, False])
+def test_shelgon_main_end_to_end(tmp_path, use_engine):
+    run = _run("models/shelgon3/main.py", tmp_path, lambda d: {
+        "KVQ_SENTENCES_PATH": repr(d + "/dSentences_sentences_clean.npy"),
+        "KVQ_LATENT_CLASSES_LABELS_PATH": repr(d + "/dSentences_latent_classes_labels_clean.npy"),
+        "KVQ_LATENT_CLASSES_ONE_HOT_PATH": repr(d + "/dSentences_latent_classes_one_hot_clean.npy"),
+        "KVQ_VQ_N_E": "32", "KVQ_VQ_E_DIM": "128", "KVQ_USE_ENGINE": str(use_engine)})
+    conf = json.load(open(run + "/run_conf.json"))
+    assert conf["vq_n_e"] == 32 and conf["encoder_model_name"] == "kvq-bert-tiny" and "n_params" in conf
+    ckpt = torch.load(run + "/shelgon_ckpt_loss_recon_val_best.pth", map_location="cpu")
+    assert set(ckpt) == {"model_state_dict", "encoder_state_dict", "decoder_state_dict"}         # Trainer.py:240-249
+    assert "vector_quantizer.embedding.weight" in ckpt["model_state_dict"]
+    assert ckpt["model_state_dict"]["vector_quantizer.embedding.weight"].shape == (32, 128)
+    logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
+    stages = {k.split("/")[0] for l in logs for k in l if "/" in k}
+    assert {"train", "val", "test"} <= stages
+    tr = [l["train/loss_recon"] for l in logs if "train/loss_recon" in l]
+    assert len(tr) == 2 and tr[1] < tr[0]                                                     # it learns
+    import pandas as pd
+    df = pd.read_feather(run + "/decoded_sentences.feather")
+    assert {"epoch", "stage", "input_sentence", "recon_sentence"} <= set(df.columns) and len(df) > 0
+
+
+def test_bagon_main_end_to_end(tmp_path):
+    run = _run("models/bagon/main.py", tmp_path, lambda d: {
+        "KVQ_DATASET_PATH": repr(d + "/dSentences_sentences_clean.npy"),
+        "KVQ_LATENT_CLASSES_LABELS_PATH": repr(d + "/dSentences_latent_classes_labels_clean.npy"),
+        "KVQ_LATENT_CLASSES_ONE_HOT_PATH": repr(d + "/dSentences_latent_classes_one_hot_clean.npy"),
+        "KVQ_MODEL_MODE": "'dec-head-ft'"})
+    ckpt = torch.load(run + "/bagon_ckpt_loss_recon_val_best.pth", map_location="cpu")
+    assert set(ckpt) == {"model_state_dict", "encoder_state_dict", "decoder_state_dict"}
+    conf = json.load(open(run + "/run_conf.json"))
+    assert conf["model_mode"] == "dec-head-ft" and conf["n_params"]["encoder"]["n_trainable_params"] == 0
+    logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
+    assert any("test/loss_recon" in l for l in logs)
