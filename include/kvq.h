@@ -195,6 +195,18 @@ int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mas
  * P^T.dO rounded to bf16), 0 = convert-and-fma kernels (f32 probabilities).  f32 io always uses the f32 kernels. */
 int kvq_attn_set_variant(int use_dot2);
 
+/* bf16 MFMA GEMM, "NT":  C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ C when accumulate != 0), bf16 in/out, f32 accumulation.
+ * The shape of every forward projection x . W^T + b of the BERT blocks (modeling_bert.py:139-352) and, on a transposed
+ * weight copy, of their input-gradient GEMMs.  K %% 64 == 0; N, lda, ldb, ldc %% 8 == 0; 16-byte aligned operands. */
+int kvq_gemm_nt_bf16(const void* A, const void* B, const void* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                     int accumulate, void* stream);
+/* BertIntermediate in one kernel (modeling_bert.py:325-337): Hout = A.B^T + bias (saved for backward), Aout = gelu(Hout). */
+int kvq_gemm_nt_bf16_gelu(const void* A, const void* B, const void* bias, void* Hout, void* Aout, int M, int N, int K, int lda,
+                          int ldb, int ldc, void* stream);
+/* its backward through the activation: C = (A.B^T) * gelu'(H)   (A = gradient of BertOutput.dense's input, B = W2^T). */
+int kvq_gemm_nt_bf16_dgelu(const void* A, const void* B, const void* H, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                           void* stream);
+
 /* torch.optim.Adam step (models/shelgon3/main.py:91: lr, weight_decay (L2, coupled), amsgrad) on flat buffers.
  *   p, m, v [, vmax] f32; g grad_dtype (scaled by grad_scale first); shadow_bf16 (may be NULL) receives bf16(p_new).
  *   step >= 1 is the 1-based step count for bias correction.  n %% 4 == 0. */

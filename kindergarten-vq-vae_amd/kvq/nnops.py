@@ -99,3 +99,36 @@ def adam_step(p32, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_d
     check(lib().kvq_adam_step(p32.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(vmax), _p(shadow), p32.numel(),
                               io_dtype_of(g), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                               float(grad_scale), stream_ptr()), "kvq_adam_step")
+
+
+def gemm_nt(a, b, bias=None, out=None, accumulate=False):
+    """out[M,N] (= | +=) a[M,K] @ b[N,K].T (+ bias), bf16, hand-written MFMA kernel (csrc/kvq_gemm.hip)."""
+    require_gpu(a, b)
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    check(lib().kvq_gemm_nt_bf16(a.data_ptr(), b.data_ptr(), _p(bias), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
+                                 out.stride(0), int(accumulate), stream_ptr()), "kvq_gemm_nt_bf16")
+    return out
+
+
+def gemm_nt_gelu(a, b, bias):
+    """(h, gelu(h)) with h = a @ b.T + bias in one kernel (BertIntermediate)."""
+    M, K = a.shape
+    N = b.shape[0]
+    h = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    g = torch.empty_like(h)
+    check(lib().kvq_gemm_nt_bf16_gelu(a.data_ptr(), b.data_ptr(), _p(bias), h.data_ptr(), g.data_ptr(), M, N, K, a.stride(0),
+                                      b.stride(0), h.stride(0), stream_ptr()), "kvq_gemm_nt_bf16_gelu")
+    return h, g
+
+
+def gemm_nt_dgelu(a, b, h):
+    """(a @ b.T) * gelu'(h) in one kernel (input gradient of BertOutput.dense pushed through the activation)."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    check(lib().kvq_gemm_nt_bf16_dgelu(a.data_ptr(), b.data_ptr(), h.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
+                                       out.stride(0), stream_ptr()), "kvq_gemm_nt_bf16_dgelu")
+    return out
