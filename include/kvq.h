@@ -200,6 +200,9 @@ int kvq_attn_set_variant(int use_dot2);
  * weight copy, of their input-gradient GEMMs.  K %% 64 == 0; N, lda, ldb, ldc %% 8 == 0; 16-byte aligned operands. */
 int kvq_gemm_nt_bf16(const void* A, const void* B, const void* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                      int accumulate, void* stream);
+/* LDS pipeline depth of the GEMM kernel: 2 (default; 64 KiB, 2 workgroups/CU) or 3 (two k-tiles in flight behind a counted
+ * s_waitcnt vmcnt + raw s_barrier, 96 KiB, 1 workgroup/CU; measured 25-40 % slower on this model's shapes). */
+int kvq_gemm_set_stages(int stages);
 /* BertIntermediate in one kernel (modeling_bert.py:325-337): Hout = A.B^T + bias (saved for backward), Aout = gelu(Hout). */
 int kvq_gemm_nt_bf16_gelu(const void* A, const void* B, const void* bias, void* Hout, void* Aout, int M, int N, int K, int lda,
                           int ldb, int ldc, void* stream);

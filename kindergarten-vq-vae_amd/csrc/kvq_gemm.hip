@@ -210,11 +210,153 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_bf16_kernel(GemmParams p
     }
 }
 
+// 3-stage variant: two k-tiles of LDS-DMA stay in flight across the barrier (counted s_waitcnt vmcnt, raw s_barrier), which is
+// what covers the L2 latency of the 12..48-tile contractions of this model; 96 KiB of LDS, one workgroup per CU.
+__global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_bf16_kernel3(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    // XCD-aware tile numbering (bijective only when ntiles % 8 == 0; otherwise plain order)
+    int id = blockIdx.x;
+    if ((p.ntiles & 7) == 0) id = (id & 7) * (p.ntiles >> 3) + (id >> 3);
+    int tm, tn;
+    if (p.group_m > 0) {
+        const int per_group = p.group_m * p.tiles_n;
+        const int grp = id / per_group, in = id - grp * per_group;
+        const int gm0 = grp * p.group_m;
+        const int gsz = p.tiles_m - gm0 < p.group_m ? p.tiles_m - gm0 : p.group_m;
+        tm = gm0 + in % gsz;
+        tn = in / gsz;
+    } else {
+        tm = id / p.tiles_n;
+        tn = id - tm * p.tiles_n;
+    }
+    const int m0 = tm * GM, n0 = tn * GN;
+    const int nkt = p.K / GK;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = 0.f;
+
+    g_stage(p, smem, 0, m0, n0, 0, w, lane);
+    if (nkt > 1) g_stage(p, smem, 1, m0, n0, 1, w, lane);
+
+    const int frow = lane & 15, fk = lane >> 4;
+    int st = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // stage kt has landed when at most the 8 LDS-DMA instructions of stage kt+1 are still outstanding
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // the buffer of stage kt-1 is free now (every wave passed the barrier after reading it): refill it with stage kt+2
+        if (kt + 2 < nkt) g_stage(p, smem, st == 0 ? 2 : st - 1, m0, n0, kt + 2, w, lane);
+        const char* At = smem + st * G_STAGE_B;
+        const char* Bt = At + G_TILE_B;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int r = wm * 64 + mi * 16 + frow;
+                a[mi] = *reinterpret_cast<const bf16x8*>(At + r * G_ROWB + (((ks * 4 + fk) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int r = wn * 64 + ni * 16 + frow;
+                b[ni] = *reinterpret_cast<const bf16x8*>(Bt + r * G_ROWB + (((ks * 4 + fk) ^ (r & 7)) << 4));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        st = st == 2 ? 0 : st + 1;
+    }
+    __syncthreads();
+
+    // ---- epilogue: acc -> (bias) -> bf16 tile in LDS -> coalesced rows (+C) -> global
+    // lane holds, for tile (mi, ni): output row m = wm*64 + mi*16 + (lane & 15), columns n = wn*64 + ni*16 + 4*(lane >> 4) + 0..3
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int nl = wn * 64 + ni * 16 + 4 * fk;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            int nb = n0 + nl; nb = nb + 3 < p.N ? nb : (p.N >= 4 ? p.N - 4 : 0);
+            const u16x4 t = *reinterpret_cast<const u16x4*>(p.bias + nb);
+            bv.x = bf16_to_f32(t.x); bv.y = bf16_to_f32(t.y); bv.z = bf16_to_f32(t.z); bv.w = bf16_to_f32(t.w);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int ml = wm * 64 + mi * 16 + frow;
+            const f32x4 v = acc[mi][ni] + bv;
+            u16x4 o = {f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
+            *reinterpret_cast<u16x4*>(smem + ml * G_CLD + nl * 2) = o;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int cid = q * G_THREADS + tid;
+        const int r = cid >> 4, c16 = cid & 15;
+        const int m = m0 + r, n = n0 + c16 * 8;
+        if (m < p.M && n < p.N) {                                     // N % 8 == 0: a chunk is inside or outside as a whole
+            uint4 v = *reinterpret_cast<const uint4*>(smem + r * G_CLD + c16 * 16);
+            const size_t off = (size_t)m * p.ldc + n;
+            unsigned* vn = reinterpret_cast<unsigned*>(&v);
+            if (p.accumulate) {
+                const uint4 old = *reinterpret_cast<const uint4*>(p.C + off);
+                const unsigned* vo = reinterpret_cast<const unsigned*>(&old);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float lo = __uint_as_float(vn[u] << 16) + __uint_as_float(vo[u] << 16);
+                    const float hi = __uint_as_float(vn[u] & 0xffff0000u) + __uint_as_float(vo[u] & 0xffff0000u);
+                    vn[u] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                }
+            }
+            if (p.epi == EPI_DGELU) {                                  // C = (A.B^T) * gelu'(h)
+                const uint4 hh = *reinterpret_cast<const uint4*>(p.H + off);
+                const unsigned* hv = reinterpret_cast<const unsigned*>(&hh);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float lo = __uint_as_float(vn[u] << 16) * dgelu_fast(__uint_as_float(hv[u] << 16));
+                    const float hi = __uint_as_float(vn[u] & 0xffff0000u) * dgelu_fast(__uint_as_float(hv[u] & 0xffff0000u));
+                    vn[u] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                }
+            }
+            *reinterpret_cast<uint4*>(p.C + off) = v;
+            if (p.epi == EPI_GELU) {                                   // second output: a = gelu(h), h = the bf16 value just stored
+                uint4 g;
+                unsigned* gv = reinterpret_cast<unsigned*>(&g);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float lo = gelu_fast(__uint_as_float(vn[u] << 16));
+                    const float hi = gelu_fast(__uint_as_float(vn[u] & 0xffff0000u));
+                    gv[u] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                }
+                *reinterpret_cast<uint4*>(p.C2 + off) = g;
+            }
+        }
+    }
+}
+
 }  // namespace kvq
 
 using namespace kvq;
 
 extern "C" {
+
+static int g_gemm_stages = 2;
+
+int kvq_gemm_set_stages(int stages) {
+    if (stages != 2 && stages != 3) return fail(KVQ_E_INVALID, "kvq_gemm_set_stages: 2 or 3");
+    g_gemm_stages = stages;
+    return KVQ_OK;
+}
 
 static int gemm_nt_launch(const void* A, const void* B, const void* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                           int accumulate, int epi, void* C2, const void* H, void* stream) {
@@ -227,6 +369,9 @@ static int gemm_nt_launch(const void* A, const void* B, const void* bias, void* 
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_B);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel3),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 3 * G_STAGE_B);
         if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
@@ -238,7 +383,10 @@ static int gemm_nt_launch(const void* A, const void* B, const void* bias, void* 
     p.ntiles = p.tiles_m * p.tiles_n;
     p.group_m = p.tiles_n > 32 ? 8 : 0;       // wide outputs (LM head): 8 tile-rows per tile-column keep the A band in L2
     p.epi = epi; p.C2 = (unsigned short*)C2; p.H = (const unsigned short*)H;
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((unsigned)p.ntiles), dim3(G_THREADS), G_LDS_B, (hipStream_t)stream, p);
+    if (g_gemm_stages == 3)
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel3, dim3((unsigned)p.ntiles), dim3(G_THREADS), 3 * G_STAGE_B, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((unsigned)p.ntiles), dim3(G_THREADS), G_LDS_B, (hipStream_t)stream, p);
     return check_launch("gemm_nt_bf16_kernel");
 }
 

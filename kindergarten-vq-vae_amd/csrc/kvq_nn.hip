@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
 
 // backward: g_pre = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  g_resid = g_pre;
 //           g_y = g_pre * dropout_mask/(1-p);  dgamma/dbeta partials per workgroup (summed by colsum_final_kernel)
-constexpr int LNB_ROWS = 16;   // rows per workgroup (4 waves x 2 rows): 1024 workgroups at N = 8192
+constexpr int LNB_ROWS = 8;    // rows per workgroup (4 waves x 2 rows): 1024 workgroups at N = 8192
 
 template <int DT, int PER>
 __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ g_out, const void* __restrict__ pre,

@@ -36,10 +36,16 @@ for (N, K) in [(768, 768), (2304, 768), (3072, 768), (768, 3072), (1536, 768), (
     c1 = c0.clone()
     nnops.gemm_nt(a, w, None, out=c1, accumulate=True)
     err_acc = (c1.float() - (c0.float() + a.float() @ w.float().t())).abs().max().item() / ref.abs().max().item()
+    from kvq import _ffi
+    _ffi.lib().kvq_gemm_set_stages(2)
+    us_own2 = t(lambda: nnops.gemm_nt(a, w, bias, out=out))
+    _ffi.lib().kvq_gemm_set_stages(3)
+    out3 = nnops.gemm_nt(a, w, bias)
+    assert torch.equal(out3, out), "3-stage result differs from 2-stage"
     us_own = t(lambda: nnops.gemm_nt(a, w, bias, out=out))
     us_ref = t(lambda: torch.addmm(bias, a, w.t(), out=base))
     fl = 2.0 * M * N * K
-    print(f"N={N:6d} K={K:5d}: own {us_own:7.1f} us {fl/us_own/1e6:6.0f} TF (rel err {err:.1e}, acc {err_acc:.1e}) | torch {us_ref:7.1f} us {fl/us_ref/1e6:6.0f} TF (rel err {err_b:.1e})", flush=True)
+    print(f"N={N:6d} K={K:5d}: own2 {us_own2:7.1f} us | own3 {us_own:7.1f} us {fl/us_own/1e6:6.0f} TF (rel err {err:.1e}, acc {err_acc:.1e}) | torch {us_ref:7.1f} us {fl/us_ref/1e6:6.0f} TF (rel err {err_b:.1e})", flush=True)
 
 import torch.nn.functional as F
 a = torch.randn(M, 768, device="cuda").bfloat16(); w = (torch.randn(3072, 768, device="cuda") * 0.05).bfloat16(); bias = torch.randn(3072, device="cuda").bfloat16()
