@@ -1,17 +1,21 @@
-"""Token accuracy (counterpart of the reference's common/metrics.py:8-36).
+"""Token accuracy of a reconstruction -- the contract of the reference's common/metrics.py:8-36.
 
-In the training step the per-batch accuracy comes for free out of the fused loss kernel (kvq_ce_forward);
-this torch version serves callers that hold id tensors only (analyses, tests)."""
+In the training step the per-batch value comes for free out of the fused loss kernel (kvq_ce_forward); this torch
+version serves callers that only hold id tensors (analyses, tests)."""
 import torch
 from torch import Tensor
 
 
+def _check_ids(name: str, t: Tensor):
+    if t.is_floating_point():
+        raise AssertionError(f"{name} tensor must be integer type, not floating point")
+
+
 def seq_acc(input: Tensor, target: Tensor):
-    """(accuracy over all tokens of the batch, accuracy per sentence).  Integer tensors of equal shape."""
-    assert input.shape == target.shape, "input and target shapes must match"
-    assert not input.is_floating_point(), "input tensor must be integer type, not floating point"
-    assert not target.is_floating_point(), "target tensor must be integer type, not floating point"
-    same = input == target
-    acc_per_batch = same.sum() / input.numel()
-    acc_per_sentence = same.float().mean(dim=-1)
-    return acc_per_batch, acc_per_sentence
+    """Returns (accuracy over every token of the batch, accuracy of each sentence [B]) for id tensors of one shape."""
+    if input.shape != target.shape:
+        raise AssertionError("input and target shapes must match")
+    _check_ids("input", input)
+    _check_ids("target", target)
+    hits = torch.eq(input, target)
+    return hits.sum() / hits.numel(), hits.to(torch.float32).mean(dim=-1)
