@@ -191,9 +191,10 @@ int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mas
                  int Sk, int dh, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed,
                  uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v, void* stream);
 
-/* bf16 attention flavour: 1 (default) = packed-dot kernels (v_dot2c_f32_bf16; probabilities / dS enter P.V, dS.K, dS^T.Q,
- * P^T.dO rounded to bf16), 0 = convert-and-fma kernels (f32 probabilities).  f32 io always uses the f32 kernels. */
-int kvq_attn_set_variant(int use_dot2);
+/* bf16 attention flavour: 2 (default) = MFMA kernels (v_mfma_f32_32x32x16_bf16 for all five products), 1 = packed-dot
+ * kernels (v_dot2c_f32_bf16); both round probabilities / dS to bf16 before P.V, dS.K, dS^T.Q, P^T.dO.  0 = convert-and-fma
+ * kernels (f32 probabilities).  All flavours draw the same dropout mask.  f32 io always uses the f32 kernels. */
+int kvq_attn_set_variant(int variant);
 
 /* bf16 MFMA GEMM, "NT":  C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ C when accumulate != 0), bf16 in/out, f32 accumulation.
  * The shape of every forward projection x . W^T + b of the BERT blocks (modeling_bert.py:139-352) and, on a transposed

@@ -429,13 +429,20 @@ __device__ __forceinline__ void stage_row(const void* base, size_t row_off, bool
     }
 }
 
-// dropout keep-scales of prob elements (b, head, i, j = 16h .. 16h+15): element index ((bh*32 + i)*32 + j), 4 per Philox call
+// Which key a lane's score slot jj (0..15) belongs to.  LAY 0: lane (query i, half h) owns keys 16h .. 16h+15 (the LDS-tile
+// kernels).  LAY 1: the C/D layout of v_mfma_f32_32x32x16_bf16 with the query on the lane: slot jj <-> key 8(jj>>2) + 4h + (jj&3).
+template <int LAY>
+__device__ __forceinline__ int attn_key(int h, int jj) { return LAY ? 8 * (jj >> 2) + 4 * h + (jj & 3) : 16 * h + jj; }
+
+// dropout keep-scales of the lane's 16 prob elements (b, head, i, j): element index ((bh*32 + i)*32 + j), 4 per Philox call
+// (both layouts own keys in aligned groups of four, so every flavour of the kernels draws the same mask)
+template <int LAY = 0>
 __device__ __forceinline__ void attn_keep16(const AttnParams& p, int bh, int i, int h, float (&keep)[16]) {
     const float inv_keep = 1.0f / (1.0f - p.p_drop);
-    const unsigned long long e4 = (((unsigned long long)bh * AT_S + i) * AT_S + 16 * h) >> 2;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const U4 r = drop_bits(p.seed, p.site, e4 + c);
+        const unsigned long long e4 = (((unsigned long long)bh * AT_S + i) * AT_S + attn_key<LAY>(h, 4 * c)) >> 2;
+        const U4 r = drop_bits(p.seed, p.site, e4);
         keep[4 * c] = keep_scale(r.x, p.thresh, inv_keep); keep[4 * c + 1] = keep_scale(r.y, p.thresh, inv_keep);
         keep[4 * c + 2] = keep_scale(r.z, p.thresh, inv_keep); keep[4 * c + 3] = keep_scale(r.w, p.thresh, inv_keep);
     }
@@ -475,7 +482,8 @@ __device__ __forceinline__ void weighted_rows32(const float* C, int cs, const T*
     }
 }
 
-// scaled + masked scores -> probabilities (before dropout) of query i against keys 16h..16h+15, and the row's lse
+// scaled + masked scores -> probabilities (before dropout) of query i against the lane's 16 keys, and the row's lse
+template <int LAY = 0>
 __device__ __forceinline__ void scores_to_probs(const AttnParams& p, int b, int i, int h, bool qvalid, float (&s)[16], float& lse_out) {
     // key-padding mask as one wave-wide bit mask: lane l < 32 loads mask[b][min(l, Sk-1)] unconditionally, ballot collects
     unsigned long long kmask = ~0ull;
@@ -487,7 +495,7 @@ __device__ __forceinline__ void scores_to_probs(const AttnParams& p, int b, int 
     float mx = -INFINITY;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
-        const int j = 16 * h + jj;
+        const int j = attn_key<LAY>(h, jj);
         bool ok = j < p.Sk && qvalid && ((kmask >> j) & 1ull);
         if (p.causal) ok = ok && j <= i;
         s[jj] = ok ? s[jj] * p.scale : -INFINITY;
@@ -855,6 +863,212 @@ __global__ __launch_bounds__(64) void attn_bwd_bf16_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 MFMA path (default): one wave per (batch, head), every product on v_mfma_f32_32x32x16_bf16.
+//   S^T = K.Q^T and dP~^T = V.dO^T contract over d: both operands are 16-byte row chunks straight from global memory.
+//   The results sit with the QUERY on the lane and 16 keys in the registers (LAY 1), so softmax / dropout / delta are
+//   lane-local (+ one cross-half exchange) and P~ / dS feed the products that contract over keys (O^T = V^T.P~^T, dQ^T = K^T.dS^T)
+//   directly as the B operand, in the permuted k order  element t of half h <-> key 16s + 8(t>>2) + 4h + (t&3).
+//   Their A operands (V^T, K^T: k-strided) come from pair-interleaved LDS tiles Xt[row/2][d] = (X[2r][d] | X[2r+1][d] << 16).
+//   dK^T = Q^T.dS and dV^T = dO^T.P~ contract over queries (the lane index of dS): dS / P~ go through a packed bf16
+//   [key][query] LDS image once and come back as natural-order B fragments (ds_read_b128).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int AM_LDT = 72;   // dwords per row of the pair-interleaved tiles (64 + 8: conflict-free 16-byte staging writes)
+constexpr int AM_LDX = 20;   // dwords per row of the packed [key][query] images (16 + 4)
+
+__device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, a), __builtin_bit_cast(abf16x8, b), c, 0, 0, 0);
+}
+// lane (row r, half h): the four chunks X[r][16s + 8h .. 16s + 8h + 7], s = 0..3 = the A/B fragments of the d-contractions
+__device__ __forceinline__ void load_row_chunks(const void* base, size_t row_off, int h, bool valid, uint4 (&f)[4]) {
+    const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + row_off + 8 * h;
+    const unsigned m = valid ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p + 16 * s);
+        f[s].x = t.x & m; f[s].y = t.y & m; f[s].z = t.z & m; f[s].w = t.w & m;
+    }
+}
+// the same chunks -> pair-interleaved tile: even lanes emit the first four d of each chunk, odd lanes the last four
+__device__ __forceinline__ void stage_pairs_from_chunks(unsigned* Xt, int r, int h, const uint4 (&f)[4]) {
+    const int odd = r & 1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned k0 = odd ? f[s].z : f[s].x, k1 = odd ? f[s].w : f[s].y;     // my row, my d-range
+        const unsigned g0 = odd ? f[s].x : f[s].z, g1 = odd ? f[s].y : f[s].w;     // my row, the partner's d-range
+        const unsigned r0 = __shfl_xor(g0, 1, WAVE), r1 = __shfl_xor(g1, 1, WAVE); // partner's row, my d-range
+        const unsigned e0 = odd ? r0 : k0, e1 = odd ? r1 : k1, o0 = odd ? k0 : r0, o1 = odd ? k1 : r1;
+        uint4 w = {(e0 & 0xffffu) | (o0 << 16), (e0 >> 16) | (o0 & 0xffff0000u), (e1 & 0xffffu) | (o1 << 16), (e1 >> 16) | (o1 & 0xffff0000u)};
+        *reinterpret_cast<uint4*>(Xt + (r >> 1) * AM_LDT + 16 * s + 8 * h + 4 * odd) = w;
+    }
+}
+// A fragment X^T[d = dcol][k] of k-step st from a pair-interleaved tile.  PERM 1: the permuted k order of an accumulator
+// used as B operand; PERM 0: natural order k = 16 st + 8h + t.
+template <int PERM>
+__device__ __forceinline__ uint4 frag_from_pairs(const unsigned* Xt, int dcol, int h, int st) {
+    uint4 a;
+    if (PERM) {
+        const unsigned* b = Xt + (8 * st + 2 * h) * AM_LDT + dcol;
+        a.x = b[0]; a.y = b[AM_LDT]; a.z = b[4 * AM_LDT]; a.w = b[5 * AM_LDT];
+    } else {
+        const unsigned* b = Xt + (8 * st + 4 * h) * AM_LDT + dcol;
+        a.x = b[0]; a.y = b[AM_LDT]; a.z = b[2 * AM_LDT]; a.w = b[3 * AM_LDT];
+    }
+    return a;
+}
+// accumulator-layout values x[16] (row r on the lane) -> the two B fragments of the key contraction
+__device__ __forceinline__ void acc_to_frags(const float (&x)[16], uint4 (&f)[2]) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        f[st].x = pack_bf16(x[8 * st], x[8 * st + 1]); f[st].y = pack_bf16(x[8 * st + 2], x[8 * st + 3]);
+        f[st].z = pack_bf16(x[8 * st + 4], x[8 * st + 5]); f[st].w = pack_bf16(x[8 * st + 6], x[8 * st + 7]);
+    }
+}
+// accumulator-layout values x (query r on the lane, key 8g + 4h + t in slot 4g + t) -> packed image T[key][query pair]
+__device__ __forceinline__ void stage_transposed(unsigned* T, int r, int h, const float (&x)[16]) {
+    const int odd = r & 1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const unsigned m01 = pack_bf16(x[4 * g], x[4 * g + 1]), m23 = pack_bf16(x[4 * g + 2], x[4 * g + 3]);
+        const unsigned got = __shfl_xor(odd ? m01 : m23, 1, WAVE);
+        const unsigned mine = odd ? m23 : m01;
+        const unsigned ev = odd ? got : mine, od = odd ? mine : got;     // the even / odd query's values of my two keys
+        const int j = 8 * g + 4 * h + 2 * odd;
+        T[j * AM_LDX + (r >> 1)] = (ev & 0xffffu) | (od << 16);
+        T[(j + 1) * AM_LDX + (r >> 1)] = (ev >> 16) | (od & 0xffff0000u);
+    }
+}
+// C tile of a [d][row] product (row r on the lane, d = d_base + 8g + 4h + t in register 4g + t): four 8-byte stores
+__device__ __forceinline__ void store_ct(void* base, size_t row_off, int h, int d_base, const f32x16& c) {
+    unsigned short* p = reinterpret_cast<unsigned short*>(base) + row_off + d_base + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint2 w = {pack_bf16(c[4 * g], c[4 * g + 1]), pack_bf16(c[4 * g + 2], c[4 * g + 3])};
+        *reinterpret_cast<uint2*>(p + 8 * g) = w;
+    }
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) z[v] = 0.f;
+    return z;
+}
+
+__global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned Vt[16 * AM_LDT];
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+    const bool kvalid = r < p.Sk, qvalid = r < p.Sq;
+    const int rk = kvalid ? r : p.Sk - 1, rq = qvalid ? r : p.Sq - 1;
+    uint4 kf[4], qf[4], vf[4];
+    load_row_chunks(p.k, ((size_t)b * p.Sk + rk) * p.ldk + hd * AT_D, h, kvalid, kf);
+    load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
+    load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma32(kf[s], qf[s], acc);      // S^T[key][query]
+    stage_pairs_from_chunks(Vt, r, h, vf);
+    float s[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) s[v] = acc[v];
+    float lse;
+    scores_to_probs<1>(p, b, r, h, qvalid, s, lse);
+    if (p.p_drop > 0.f) {
+        float keep[16];
+        attn_keep16<1>(p, bh, r, h, keep);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s[v] *= keep[v];
+    }
+    uint4 pf[2];
+    acc_to_frags(s, pf);
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        f32x16 o = zero16();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<1>(Vt, 32 * dt + r, h, st), pf[st], o);   // O^T[d][query]
+        if (qvalid) store_ct(p.out, ((size_t)b * p.Sq + r) * p.ldo + hd * AT_D, h, 32 * dt, o);
+    }
+    if (qvalid && h == 0 && p.lse) p.lse[((size_t)b * p.nh + hd) * p.Sq + r] = lse;
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned Kt[16 * AM_LDT], Qt[16 * AM_LDT], Gt[16 * AM_LDT];
+    __shared__ __attribute__((aligned(16))) unsigned TD[AT_S * AM_LDX], TP[AT_S * AM_LDX];
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+    const bool kvalid = r < p.Sk, qvalid = r < p.Sq;
+    const int rk = kvalid ? r : p.Sk - 1, rq = qvalid ? r : p.Sq - 1;
+    uint4 kf[4], qf[4], vf[4], gf[4];
+    load_row_chunks(p.k, ((size_t)b * p.Sk + rk) * p.ldk + hd * AT_D, h, kvalid, kf);
+    load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
+    load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
+    load_row_chunks(p.g_out, ((size_t)b * p.Sq + rq) * p.ldo + hd * AT_D, h, qvalid, gf);
+    f32x16 accS = zero16(), accP = zero16();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) accS = mfma32(kf[s], qf[s], accS);     // S^T[key][query]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) accP = mfma32(vf[s], gf[s], accP);     // dP~^T[key][query] = V[key] . dO[query]
+    stage_pairs_from_chunks(Kt, r, h, kf);
+    stage_pairs_from_chunks(Qt, r, h, qf);
+    stage_pairs_from_chunks(Gt, r, h, gf);
+    float s[16], dp[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { s[v] = accS[v]; dp[v] = accP[v]; }
+    float lse;
+    scores_to_probs<1>(p, b, r, h, qvalid, s, lse);
+    float keep[16];
+    if (p.p_drop > 0.f) attn_keep16<1>(p, bh, r, h, keep);
+    else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) keep[v] = 1.0f;
+    }
+    float delta = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        dp[v] *= keep[v];
+        delta += s[v] * dp[v];
+    }
+    delta += __shfl_xor(delta, 32, WAVE);
+    float ds[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        ds[v] = s[v] * (dp[v] - delta) * p.scale;
+        s[v] *= keep[v];                                    // P~
+    }
+    stage_transposed(TD, r, h, ds);
+    stage_transposed(TP, r, h, s);
+    uint4 dsf[2];
+    acc_to_frags(ds, dsf);
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {                        // dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
+        f32x16 o = zero16();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<1>(Kt, 32 * dt + r, h, st), dsf[st], o);
+        if (qvalid) store_ct(p.g_q, ((size_t)b * p.Sq + r) * p.ldq + hd * AT_D, h, 32 * dt, o);
+    }
+    uint4 tdf[2], tpf[2];                                   // lane = key r: dS[query 16st + 8h + t][r], P~[..][r]
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        tdf[st] = *reinterpret_cast<const uint4*>(TD + r * AM_LDX + 8 * st + 4 * h);
+        tpf[st] = *reinterpret_cast<const uint4*>(TP + r * AM_LDX + 8 * st + 4 * h);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {                        // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key];  dV^T = dO^T . P~
+        f32x16 o = zero16();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<0>(Qt, 32 * dt + r, h, st), tdf[st], o);
+        if (kvalid) store_ct(p.g_k, ((size_t)b * p.Sk + r) * p.ldk + hd * AT_D, h, 32 * dt, o);
+        o = zero16();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<0>(Gt, 32 * dt + r, h, st), tpf[st], o);
+        if (kvalid) store_ct(p.g_v, ((size_t)b * p.Sk + r) * p.ldv + hd * AT_D, h, 32 * dt, o);
+    }
+}
+
 }  // namespace kvq
 
 using namespace kvq;
@@ -1007,10 +1221,11 @@ int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void
     return check_launch("adam_kernel");
 }
 
-static int g_attn_dot2 = 1;   // bf16 io: 1 = packed-dot kernels (v_dot2c_f32_bf16), 0 = convert-and-fma kernels
+static int g_attn_variant = 2;   // bf16 io: 2 = MFMA kernels, 1 = packed-dot kernels (v_dot2c_f32_bf16), 0 = convert-and-fma kernels
 
-int kvq_attn_set_variant(int use_dot2) {
-    g_attn_dot2 = use_dot2 ? 1 : 0;
+int kvq_attn_set_variant(int variant) {
+    KVQ_REQUIRE(variant >= 0 && variant <= 2, "kvq_attn_set_variant: variant %d unknown (0 fma, 1 dot2, 2 mfma)", variant);
+    g_attn_variant = variant;
     return KVQ_OK;
 }
 
@@ -1035,7 +1250,8 @@ int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mas
     hipStream_t st = (hipStream_t)stream;
     const bool al = (ldq % 8 == 0) && (ldk % 8 == 0) && (ldv % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0);
     if (io_dtype == KVQ_F32) hipLaunchKernelGGL(attn_fwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
-    else if (al && g_attn_dot2) hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else if (al && g_attn_variant == 2) hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else if (al && g_attn_variant == 1) hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     return check_launch("attn_fwd_kernel");
 }
@@ -1054,7 +1270,8 @@ int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mas
     const bool al = (ldq % 8 == 0) && (ldk % 8 == 0) && (ldv % 8 == 0) && (ldo % 8 == 0) &&
                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)g_out | (uintptr_t)g_q | (uintptr_t)g_k | (uintptr_t)g_v) % 16 == 0);
     if (io_dtype == KVQ_F32) hipLaunchKernelGGL(attn_bwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
-    else if (al && g_attn_dot2) hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else if (al && g_attn_variant == 2) hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else if (al && g_attn_variant == 1) hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     return check_launch("attn_bwd_kernel");
 }

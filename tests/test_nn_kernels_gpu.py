@@ -136,11 +136,12 @@ def _ref_attention(q, k, v, mask, causal, keep=None, p=0.0):
 
 @pytest.mark.parametrize("B,nh,Sq,Sk,causal,masked", [(3, 12, 32, 32, False, True), (2, 4, 32, 32, True, True), (2, 3, 12, 12, True, True),
                                                       (2, 2, 7, 32, False, False), (1, 1, 32, 5, False, False)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, "bf16-fma"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, "bf16-dot2", "bf16-fma"])
 def test_attention_fwd_bwd(ops, B, nh, Sq, Sk, causal, masked, dtype):
     from kvq import _ffi
-    _ffi.lib().kvq_attn_set_variant(0 if dtype == "bf16-fma" else 1)     # bf16: packed-dot kernels (default) or convert+fma
-    dtype = torch.bfloat16 if dtype == "bf16-fma" else dtype
+    # bf16 flavours: MFMA kernels (default, 2), packed-dot kernels (1), convert+fma kernels (0)
+    assert _ffi.lib().kvq_attn_set_variant({"bf16-fma": 0, "bf16-dot2": 1}.get(dtype, 2)) == 0
+    dtype = torch.bfloat16 if isinstance(dtype, str) else dtype
     torch.manual_seed(B * 100 + Sq)
     H = nh * 64
     qkv = torch.randn(B * Sq, 3 * H, device="cuda").to(dtype)        # fused QKV layout: strided q/k/v views
@@ -173,11 +174,11 @@ def test_attention_fwd_bwd(ops, B, nh, Sq, Sk, causal, masked, dtype):
     torch.testing.assert_close(gq.float(), unh(qr.grad, Sq), **t)
     torch.testing.assert_close(gk.float(), unh(kr.grad, Sk), **t)
     torch.testing.assert_close(gv.float(), unh(vr.grad, Sk), **t)
-    _ffi.lib().kvq_attn_set_variant(1)
+    _ffi.lib().kvq_attn_set_variant(2)
 
 
 def test_attention_bf16_dropout_same_mask_in_both_flavours(ops):
-    """The packed-dot and the convert+fma bf16 kernels draw the same Philox mask: outputs agree to bf16 rounding."""
+    """The MFMA, packed-dot and convert+fma bf16 kernels draw the same Philox mask: outputs agree to bf16 rounding."""
     from kvq import _ffi
     torch.manual_seed(11)
     B, nh, S, H = 4, 12, 32, 768
@@ -185,15 +186,17 @@ def test_attention_bf16_dropout_same_mask_in_both_flavours(ops):
     g = torch.randn(B * S, H, device="cuda").bfloat16()
     mask = (torch.arange(S, device="cuda")[None] < torch.tensor([32, 9, 20, 4], device="cuda")[:, None]).long()
     outs = []
-    for flavour in (1, 0):
+    for flavour in (2, 1, 0):
         _ffi.lib().kvq_attn_set_variant(flavour)
         ctx, _ = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, B, nh, S, S, True, 0.1, seed=5, site=2)
         gq = torch.zeros_like(qkv)
         ops.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, g, B, nh, S, S, True, 0.1, 5, 2, gq[:, :H], gq[:, H:2 * H], gq[:, 2 * H:])
         outs.append((ctx.float(), gq.float()))
-    _ffi.lib().kvq_attn_set_variant(1)
-    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=3e-2, atol=3e-2)
-    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=5e-2, atol=5e-2)
+    _ffi.lib().kvq_attn_set_variant(2)
+    assert _ffi.lib().kvq_attn_set_variant(3) != 0          # unknown flavour is refused, the selection stays
+    for other in (1, 2):
+        torch.testing.assert_close(outs[0][0], outs[other][0], rtol=3e-2, atol=3e-2)
+        torch.testing.assert_close(outs[0][1], outs[other][1], rtol=5e-2, atol=5e-2)
 
 
 def test_attention_dropout_mask_consistency(ops):
