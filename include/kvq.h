@@ -174,6 +174,34 @@ size_t kvq_colsum_workspace_bytes(int64_t N, int64_t C);
 int kvq_colsum(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, void* out, int out_dtype, float scale,
                int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* Batched reductions (one launch for many small sums): item i computes
+ *   dst[c] = scale * sum_{p < count} src[p*ld + c] (+ dst[c] when accumulate != 0),  c < cols.
+ * The backward of one BERT layer yields 8-14 of these (split-K slabs of the weight-gradient GEMMs, per-workgroup partials of
+ * the LayerNorm gamma/beta and bias gradients: kvq_*_partial below); run one by one each is a launch-latency-bound kernel.
+ * Rows are summed in index order, so results are deterministic.  Long rows with count <= 32 (split-K slabs) take a
+ * vectorised path when cols, ld %% 4 == 0 and src/dst are aligned to four elements. */
+#define KVQ_REDUCE_MAX_ITEMS 16
+typedef struct kvq_reduce_item {
+    const void* src;
+    void* dst;
+    int64_t count, cols, ld;
+    float scale;
+    int32_t src_dtype, dst_dtype, accumulate;
+} kvq_reduce_item;
+int kvq_reduce_batch(const kvq_reduce_item* items, int n, void* stream);
+
+/* First halves of kvq_dropout_residual_ln_bwd / kvq_colsum: everything except the final sums over the partial rows, which the
+ * caller hands to kvq_reduce_batch.  LayerNorm partials: part [kvq_ln_bwd_partial_rows(N)][3H] f32 = [dbias_prev | dgamma | dbeta]
+ * (the dbias_prev third only when want_dbias); column-sum partials: part [kvq_colsum_partial_rows(N)][C] f32.
+ * part_bytes >= kvq_ln_bwd_workspace_bytes(N,H) / kvq_colsum_workspace_bytes(N,C). */
+int64_t kvq_ln_bwd_partial_rows(int64_t N);
+int kvq_dropout_residual_ln_bwd_partial(const void* g_out, const void* pre, const float* mean, const float* rstd,
+                                        const float* gamma, int64_t N, int H, float p_drop, uint64_t seed, uint32_t site,
+                                        int io_dtype, void* g_y, void* g_resid, int want_dbias, void* part, size_t part_bytes,
+                                        void* stream);
+int64_t kvq_colsum_partial_rows(int64_t N);
+int kvq_colsum_partial(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, void* part, size_t part_bytes, void* stream);
+
 /* out[i] = sum_s part[s*n + i], f32 accumulate: combines the S split-K slabs of a weight-gradient GEMM.  n %% 4 == 0. */
 int kvq_sum_slabs(const void* part, int S, int64_t n, int io_dtype, void* out, void* stream);
 

@@ -291,6 +291,88 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const void* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Batched reductions: up to KVQ_REDUCE_MAX_ITEMS independent  dst[c] = scale * sum_{p < count} src[p*ld + c] (+ dst[c])
+// in ONE launch.  A backward layer produces ~8-14 such sums (split-K slabs of the weight-gradient GEMMs, the per-workgroup
+// partials of the LayerNorm and bias gradients); each one alone is a 5-8 us launch-latency-bound kernel.
+//   count <= 32 ("slabs", long rows):  1024 threads x 8 columns per workgroup, slabs summed in order
+//   count  > 32 ("tree", short rows):  64 columns per workgroup, 16 row phases, fixed summation order
+// ---------------------------------------------------------------------------------------------------------------
+struct ReduceBatch {
+    kvq_reduce_item it[KVQ_REDUCE_MAX_ITEMS];
+    int first_block[KVQ_REDUCE_MAX_ITEMS + 1];
+    int n;
+};
+constexpr int RB_SLAB_COLS = 8192;   // columns per workgroup in slab mode
+__host__ __device__ __forceinline__ bool reduce_is_slab(const kvq_reduce_item& d) {   // needs 4-element vector access
+    const uintptr_t sa = d.src_dtype == KVQ_F32 ? 15 : 7, da = d.dst_dtype == KVQ_F32 ? 15 : 7;
+    return d.count <= 32 && d.cols % 4 == 0 && d.ld % 4 == 0 && ((uintptr_t)d.src & sa) == 0 && ((uintptr_t)d.dst & da) == 0;
+}
+
+template <int DT_SRC, int DT_DST>
+__device__ __forceinline__ void reduce_slab_block(const kvq_reduce_item& d, int blk) {
+    const int64_t c0 = (int64_t)blk * RB_SLAB_COLS + 4 * threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t c = c0 + 4096 * u;
+        if (c < d.cols) {
+            f32x4 a = IO<DT_SRC>::load4(d.src, c);
+            for (int64_t p = 1; p < d.count; ++p) a += IO<DT_SRC>::load4(d.src, (size_t)p * d.ld + c);
+            a *= d.scale;
+            if (d.accumulate) a += IO<DT_DST>::load4(d.dst, c);
+            IO<DT_DST>::store4(d.dst, c, a);
+        }
+    }
+}
+template <int DT_SRC, int DT_DST>
+__device__ __forceinline__ void reduce_tree_block(const kvq_reduce_item& d, int blk, float (*red)[64]) {
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blk * 64 + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < d.cols) {
+        int64_t p = ph;
+        for (; p + 16 < d.count; p += 32) {
+            a0 += IO<DT_SRC>::load1(d.src, (size_t)p * d.ld + c);
+            a1 += IO<DT_SRC>::load1(d.src, (size_t)(p + 16) * d.ld + c);
+        }
+        for (; p < d.count; p += 16) a0 += IO<DT_SRC>::load1(d.src, (size_t)p * d.ld + c);
+    }
+    red[ph][cl] = a0 + a1;
+    __syncthreads();
+    if (ph == 0 && c < d.cols) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += red[q][cl];
+        a *= d.scale;
+        if (d.accumulate) a += IO<DT_DST>::load1(d.dst, c);
+        IO<DT_DST>::store1(d.dst, c, a);
+    }
+}
+
+__global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceBatch rb) {
+    __shared__ float red[16][64];
+    int i = 0;
+    while (i + 1 < rb.n && (int)blockIdx.x >= rb.first_block[i + 1]) ++i;      // block-uniform
+    const kvq_reduce_item& d = rb.it[i];
+    const int blk = (int)blockIdx.x - rb.first_block[i];
+    const int combo = (d.src_dtype == KVQ_F32 ? 0 : 2) | (d.dst_dtype == KVQ_F32 ? 0 : 1);
+    if (reduce_is_slab(d)) {
+        switch (combo) {
+            case 0: reduce_slab_block<KVQ_F32, KVQ_F32>(d, blk); break;
+            case 1: reduce_slab_block<KVQ_F32, KVQ_BF16>(d, blk); break;
+            case 2: reduce_slab_block<KVQ_BF16, KVQ_F32>(d, blk); break;
+            default: reduce_slab_block<KVQ_BF16, KVQ_BF16>(d, blk); break;
+        }
+    } else {
+        switch (combo) {
+            case 0: reduce_tree_block<KVQ_F32, KVQ_F32>(d, blk, red); break;
+            case 1: reduce_tree_block<KVQ_F32, KVQ_BF16>(d, blk, red); break;
+            case 2: reduce_tree_block<KVQ_BF16, KVQ_F32>(d, blk, red); break;
+            default: reduce_tree_block<KVQ_BF16, KVQ_BF16>(d, blk, red); break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // GELU (erf form), elementwise.  fwd: a = gelu(h);  bwd: g_h = g_a * gelu'(h)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -1112,30 +1194,42 @@ static int colsum_f32_partials(const float* part, int64_t P, int64_t C, int64_t 
     return check_launch("colsum_final_kernel");
 }
 
-int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float* mean, const float* rstd, const float* gamma,
-                                int64_t N, int H, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* g_y,
-                                void* g_resid, void* g_gamma, void* g_beta, void* g_bias_prev, int param_grad_dtype, int accumulate,
-                                void* ws, size_t ws_bytes, void* stream) {
+int64_t kvq_ln_bwd_partial_rows(int64_t N) { return (N + LNB_ROWS - 1) / LNB_ROWS; }
+
+int kvq_dropout_residual_ln_bwd_partial(const void* g_out, const void* pre, const float* mean, const float* rstd,
+                                        const float* gamma, int64_t N, int H, float p_drop, uint64_t seed, uint32_t site,
+                                        int io_dtype, void* g_y, void* g_resid, int want_dbias, void* part, size_t part_bytes,
+                                        void* stream) {
     KVQ_REQUIRE(g_out && pre && mean && rstd && gamma && N > 0 && H > 0, "kvq_dropout_residual_ln_bwd: bad argument");
     KVQ_REQUIRE(H % 4 == 0 && H <= 3072, "kvq_dropout_residual_ln_bwd: H=%d unsupported (multiple of 4, <= 3072: 48*H bytes of LDS)", H);
     KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
     const size_t need = kvq_ln_bwd_workspace_bytes(N, H);
-    if (!ws || ws_bytes < need) return fail(KVQ_E_WORKSPACE, "kvq_dropout_residual_ln_bwd: workspace %zu < %zu", ws_bytes, need);
+    if (!part || part_bytes < need) return fail(KVQ_E_WORKSPACE, "kvq_dropout_residual_ln_bwd: workspace %zu < %zu", part_bytes, need);
+    KVQ_REQUIRE(!want_dbias || g_y, "kvq_dropout_residual_ln_bwd: the dense-bias partials need g_y");
     hipStream_t st = (hipStream_t)stream;
     const int64_t blocks = (N + LNB_ROWS - 1) / LNB_ROWS;
-    KVQ_REQUIRE(!g_bias_prev || g_y, "kvq_dropout_residual_ln_bwd: g_bias_prev needs g_y");
-    float* pdg = (float*)ws;
-    const int want_dbias = g_bias_prev ? 1 : 0;
+    float* pdg = (float*)part;
     const size_t lds = (size_t)4 * 3 * H * sizeof(float);
     const unsigned th = drop_threshold(p_drop);
 #define LAUNCH_LN_BWD(DTV, PERV)                                                                                             \
     hipLaunchKernelGGL((drln_bwd_kernel<DTV, PERV>), dim3((unsigned)blocks), dim3(256), lds, st, g_out, pre, mean, rstd, gamma, \
-                       N, H, p_drop, th, (unsigned long long)seed, site, g_y, g_resid, pdg, want_dbias)
+                       N, H, p_drop, th, (unsigned long long)seed, site, g_y, g_resid, pdg, want_dbias ? 1 : 0)
     if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 4), LAUNCH_LN_BWD(KVQ_BF16, 4)); }
     else { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 16), LAUNCH_LN_BWD(KVQ_BF16, 16)); }
 #undef LAUNCH_LN_BWD
-    int rc = check_launch("drln_bwd_kernel");
+    return check_launch("drln_bwd_kernel");
+}
+
+int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float* mean, const float* rstd, const float* gamma,
+                                int64_t N, int H, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* g_y,
+                                void* g_resid, void* g_gamma, void* g_beta, void* g_bias_prev, int param_grad_dtype, int accumulate,
+                                void* ws, size_t ws_bytes, void* stream) {
+    int rc = kvq_dropout_residual_ln_bwd_partial(g_out, pre, mean, rstd, gamma, N, H, p_drop, seed, site, io_dtype, g_y, g_resid,
+                                                 g_bias_prev ? 1 : 0, ws, ws_bytes, stream);
     if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t blocks = (N + LNB_ROWS - 1) / LNB_ROWS;
+    float* pdg = (float*)ws;
     const size_t esz = param_grad_dtype == KVQ_F32 ? 4 : 2;
     const int64_t H3 = 3 * (int64_t)H;
     const bool gb_adj = g_gamma && g_beta && (char*)g_beta == (char*)g_gamma + (size_t)H * esz;
@@ -1159,19 +1253,47 @@ int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float*
 
 size_t kvq_colsum_workspace_bytes(int64_t N, int64_t C) { return (size_t)((N + CS_ROWS - 1) / CS_ROWS) * C * sizeof(float); }
 
-int kvq_colsum(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, void* out, int out_dtype, float scale,
-               int accumulate, void* ws, size_t ws_bytes, void* stream) {
-    KVQ_REQUIRE(x && out && N > 0 && C > 0 && ld >= C, "kvq_colsum: bad argument");
+int64_t kvq_colsum_partial_rows(int64_t N) { return (N + CS_ROWS - 1) / CS_ROWS; }
+
+int kvq_colsum_partial(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, void* part, size_t part_bytes, void* stream) {
+    KVQ_REQUIRE(x && N > 0 && C > 0 && ld >= C, "kvq_colsum: bad argument");
+    KVQ_REQUIRE(in_dtype == KVQ_F32 || in_dtype == KVQ_BF16, "unsupported io dtype %d", in_dtype);
     const size_t need = kvq_colsum_workspace_bytes(N, C);
-    if (!ws || ws_bytes < need) return fail(KVQ_E_WORKSPACE, "kvq_colsum: workspace %zu < %zu", ws_bytes, need);
+    if (!part || part_bytes < need) return fail(KVQ_E_WORKSPACE, "kvq_colsum: workspace %zu < %zu", part_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     const int64_t P = (N + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)((C + 255) / 256), (unsigned)P);
-    DISPATCH_DT(in_dtype, hipLaunchKernelGGL(colsum_partial_kernel<KVQ_F32>, grid, dim3(256), 0, st, x, N, C, ld, (float*)ws),
-                hipLaunchKernelGGL(colsum_partial_kernel<KVQ_BF16>, grid, dim3(256), 0, st, x, N, C, ld, (float*)ws));
-    int rc = check_launch("colsum_partial_kernel");
+    DISPATCH_DT(in_dtype, hipLaunchKernelGGL(colsum_partial_kernel<KVQ_F32>, grid, dim3(256), 0, st, x, N, C, ld, (float*)part),
+                hipLaunchKernelGGL(colsum_partial_kernel<KVQ_BF16>, grid, dim3(256), 0, st, x, N, C, ld, (float*)part));
+    return check_launch("colsum_partial_kernel");
+}
+
+int kvq_colsum(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, void* out, int out_dtype, float scale,
+               int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    KVQ_REQUIRE(out, "kvq_colsum: bad argument");
+    int rc = kvq_colsum_partial(x, N, C, ld, in_dtype, ws, ws_bytes, stream);
     if (rc) return rc;
-    return colsum_f32_partials((const float*)ws, P, C, C, out, out_dtype, scale, accumulate, st);
+    return colsum_f32_partials((const float*)ws, (N + CS_ROWS - 1) / CS_ROWS, C, C, out, out_dtype, scale, accumulate, (hipStream_t)stream);
+}
+
+int kvq_reduce_batch(const kvq_reduce_item* items, int n, void* stream) {
+    KVQ_REQUIRE(items && n >= 1 && n <= KVQ_REDUCE_MAX_ITEMS, "kvq_reduce_batch: 1..%d items per call", KVQ_REDUCE_MAX_ITEMS);
+    ReduceBatch rb;
+    rb.n = n;
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const kvq_reduce_item& d = items[i];
+        KVQ_REQUIRE(d.src && d.dst && d.count >= 1 && d.cols >= 1 && d.ld >= d.cols, "kvq_reduce_batch: item %d malformed", i);
+        KVQ_REQUIRE((d.src_dtype == KVQ_F32 || d.src_dtype == KVQ_BF16) && (d.dst_dtype == KVQ_F32 || d.dst_dtype == KVQ_BF16),
+                    "kvq_reduce_batch: item %d: unsupported dtype", i);
+        rb.it[i] = d;
+        rb.first_block[i] = (int)blocks;
+        blocks += reduce_is_slab(d) ? (d.cols + RB_SLAB_COLS - 1) / RB_SLAB_COLS : (d.cols + 63) / 64;
+        KVQ_REQUIRE(blocks < (1 << 30), "kvq_reduce_batch: too many workgroups");
+    }
+    rb.first_block[n] = (int)blocks;
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, rb);
+    return check_launch("reduce_batch_kernel");
 }
 
 int kvq_sum_slabs(const void* part, int S, int64_t n, int io_dtype, void* out, void* stream) {

@@ -15,6 +15,15 @@ KVQ_F32, KVQ_BF16 = 0, 1
 
 _vp, _i64, _int, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 
+KVQ_REDUCE_MAX_ITEMS = 16
+
+
+class ReduceItem(C.Structure):
+    """struct kvq_reduce_item of include/kvq.h"""
+    _fields_ = [("src", _vp), ("dst", _vp), ("count", _i64), ("cols", _i64), ("ld", _i64), ("scale", _f32),
+                ("src_dtype", C.c_int32), ("dst_dtype", C.c_int32), ("accumulate", C.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/kvq.h line by line
 SIGNATURES = {
     "kvq_version": (_int, []),
@@ -41,6 +50,12 @@ SIGNATURES = {
     "kvq_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "kvq_colsum": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _int, _f32, _int, _vp, _sz, _vp]),
     "kvq_sum_slabs": (_int, [_vp, _int, _i64, _int, _vp, _vp]),
+    "kvq_reduce_batch": (_int, [C.POINTER(ReduceItem), _int, _vp]),
+    "kvq_ln_bwd_partial_rows": (_i64, [_i64]),
+    "kvq_dropout_residual_ln_bwd_partial": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp,
+                                                   _int, _vp, _sz, _vp]),
+    "kvq_colsum_partial_rows": (_i64, [_i64]),
+    "kvq_colsum_partial": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _sz, _vp]),
     "kvq_gelu_fwd": (_int, [_vp, _vp, _i64, _int, _vp]),
     "kvq_gelu_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "kvq_attn_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32,

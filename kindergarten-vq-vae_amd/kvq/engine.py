@@ -261,13 +261,48 @@ class TrainEngine:
     # (measured with tools/gemm_probe.py on MI355X, hipBLASLt 1.0: 1.3-1.8x over the plain call)
     _SPLITS = {(768, 768): 16, (2304, 768): 8, (3072, 768): 4, (768, 3072): 4, (1536, 768): 8}
 
+    # ------------------------------------------------------------------------------------------------------------
+    # deferred small reductions: a layer's split-K slab sums and LayerNorm / bias partial sums go out as ONE launch
+    # (kvq_reduce_batch) instead of 8-14 launch-latency-bound kernels; _flush_reductions() runs before anything reads them
+    # ------------------------------------------------------------------------------------------------------------
+    def _defer(self, src, dst, count, cols, ld, src_offset=0):
+        self._red_items.append(nnops.reduce_item(src, dst, count, cols, ld, src_offset=src_offset))
+        self._red_keep.append(src)            # the partials must outlive the launch
+
+    def _flush_reductions(self):
+        if self._red_items:
+            nnops.reduce_batch(self._red_items)
+            self._red_items, self._red_keep = [], []
+
+    def _defer_colsum(self, x, dst, cols=None):
+        part = nnops.colsum_partial(x, cols)
+        self._defer(part, dst, part.shape[0], part.shape[1], part.shape[1])
+
+    def _ln_bwd(self, g_out, pre, mean, rstd, gamma, p_drop, seed, site, g_gamma, g_beta, g_bias_prev=None, need_g_resid=True):
+        """LayerNorm backward; the gamma / beta / previous-dense-bias gradients are queued as deferred reductions."""
+        g_y, g_resid, part = nnops.ln_bwd_partial(g_out, pre, mean, rstd, gamma, p_drop, seed, site, need_g_resid=need_g_resid,
+                                                  want_dbias=g_bias_prev is not None)
+        H = g_out.shape[1]
+        runs = []                                            # [column offset in part, dst, cols]: adjacent targets merge
+        for off, dst in ((0, g_bias_prev), (H, g_gamma), (2 * H, g_beta)):
+            if dst is None:
+                continue
+            if runs and runs[-1][0] + runs[-1][2] == off and \
+                    runs[-1][1].data_ptr() + runs[-1][2] * dst.element_size() == dst.data_ptr() and runs[-1][1].dtype == dst.dtype:
+                runs[-1][2] += H
+            else:
+                runs.append([off, dst, H])
+        for off, dst, cols in runs:
+            self._defer(part, dst, part.shape[0], cols, 3 * H, src_offset=off)
+        return g_y, g_resid
+
     def _wgrad(self, gy, x, out):
         Ntok, M = gy.shape
         N = x.shape[1]
         S = self._SPLITS.get((M, N), 0) if self.dtype == torch.bfloat16 else 0
         if S and Ntok % S == 0 and Ntok // S >= 256 and gy.is_contiguous() and x.is_contiguous():
             part = torch.bmm(gy.view(S, Ntok // S, M).transpose(1, 2), x.view(S, Ntok // S, N))
-            nnops.sum_slabs(part, out)
+            self._defer(part, out, S, M * N, M * N)
         else:
             torch.mm(gy.t(), x, out=out)
 
@@ -281,7 +316,7 @@ class TrainEngine:
         if fl.trainable[wnames[0]]:
             self._wgrad(gy, x, gW)
         if fl.trainable[bnames[0]] and not bias_done:     # bias_done: the LayerNorm backward kernel already produced it
-            nnops.colsum(gy, gb)
+            self._defer_colsum(gy, gb)
         if gx_accum is not None:
             gx_accum.addmm_(gy, W)
             return gx_accum
@@ -358,7 +393,7 @@ class TrainEngine:
         fl, H, nh = self.flat, self.H, self.nh
         x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk = saved
         tr = fl.trainable
-        g_ao, g_x = nnops.ln_bwd(g_out, lnpre, mean, rstd, fl.w32(pre + "ln.w"), p_hid, self._step_seed, site_o,
+        g_ao, g_x = self._ln_bwd(g_out, lnpre, mean, rstd, fl.w32(pre + "ln.w"), p_hid, self._step_seed, site_o,
                                  g_gamma=fl.g(pre + "ln.w") if tr[pre + "ln.w"] else None,
                                  g_beta=fl.g(pre + "ln.b") if tr[pre + "ln.b"] else None,
                                  g_bias_prev=fl.g(pre + "o.b") if tr[pre + "o.b"] else None)
@@ -392,7 +427,7 @@ class TrainEngine:
         fl = self.flat
         x, h, a, lnpre, mean, rstd, p_hid, site = saved
         tr = fl.trainable
-        g_f, g_x = nnops.ln_bwd(g_out, lnpre, mean, rstd, fl.w32(pre + "ln2.w"), p_hid, self._step_seed, site,
+        g_f, g_x = self._ln_bwd(g_out, lnpre, mean, rstd, fl.w32(pre + "ln2.w"), p_hid, self._step_seed, site,
                                 g_gamma=fl.g(pre + "ln2.w") if tr[pre + "ln2.w"] else None,
                                 g_beta=fl.g(pre + "ln2.b") if tr[pre + "ln2.b"] else None,
                                 g_bias_prev=fl.g(pre + "f2.b") if tr[pre + "f2.b"] else None)
@@ -405,7 +440,8 @@ class TrainEngine:
     # gradient exchange (multi-GPU): all-reduce finished tail chunks of the flat gradient buffer while backward runs
     # ------------------------------------------------------------------------------------------------------------
     def _grads_done_down_to(self, name):
-        """Every gradient located at or after segment `name` is final."""
+        """Every gradient located at or after segment `name` is final (once the queued reductions have been launched)."""
+        self._flush_reductions()
         if self.world == 1:
             return
         lo = self.flat.seg[name][0]
@@ -452,6 +488,7 @@ class TrainEngine:
         if S > 32:
             raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
         self._site_ctr = 0
+        self._red_items, self._red_keep = [], []
         self._step_seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
         mask = attention_mask.contiguous()
         ecfg, dcfg = self.ecfg, self.dcfg
@@ -510,7 +547,7 @@ class TrainEngine:
                                     self.io, logits.data_ptr(), stream_ptr()), "kvq_ce_backward")      # in place: logits := d loss / d logits
         g_logits = logits
         if tr["head.bias"]:
-            nnops.colsum(g_logits, fl.g("head.bias", rows=self.Vp))
+            self._defer_colsum(g_logits, fl.g("head.bias", rows=self.Vp))
         if tr["dec.emb.word"]:
             # [Vp,H] = g_logits^T hN is faster computed as its transpose (H rows x Vp columns) and flipped once
             gWt = torch.mm(hN.t(), g_logits)
@@ -518,7 +555,7 @@ class TrainEngine:
             del gWt
         g_hN = torch.mm(g_logits, Wv)
         del logits, g_logits
-        g_ta, _ = nnops.ln_bwd(g_hN, hpre, hmean, hrstd, fl.w32("head.ln.w"),
+        g_ta, _ = self._ln_bwd(g_hN, hpre, hmean, hrstd, fl.w32("head.ln.w"), 0.0, 0, 0,
                                g_gamma=fl.g("head.ln.w") if tr["head.ln.w"] else None,
                                g_beta=fl.g("head.ln.b") if tr["head.ln.b"] else None, need_g_resid=False)
         g_t = nnops.gelu_bwd(t, g_ta, out=g_ta)
@@ -555,6 +592,7 @@ class TrainEngine:
                 self._grads_done_down_to(f"enc.{i}.sa.q.w")
                 enc_saved[i] = None
             self._emb_bwd("enc.emb.", g_x, emb_saved)
+        self._flush_reductions()
         return out
 
     def optimizer_step(self):

@@ -55,6 +55,50 @@ def colsum(x, out, scale=1.0, accumulate=False, cols=None):
     return out
 
 
+def ln_bwd_partial(g_out, pre, mean, rstd, gamma, p_drop=0.0, seed=0, site=0, need_g_y=True, need_g_resid=True, want_dbias=False):
+    """LayerNorm backward without the final parameter-gradient sums: returns (g_y, g_resid, part) with part [rows, 3H] f32 =
+    per-workgroup partials [dbias_prev | dgamma | dbeta]; hand column ranges of `part` to reduce_batch()."""
+    N, H = g_out.shape
+    g_y = torch.empty_like(g_out) if need_g_y else None
+    g_resid = torch.empty_like(g_out) if need_g_resid else None
+    l = lib()
+    part = torch.empty((l.kvq_ln_bwd_partial_rows(N), 3 * H), dtype=torch.float32, device=g_out.device)
+    check(l.kvq_dropout_residual_ln_bwd_partial(g_out.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                                N, H, float(p_drop), int(seed), int(site), io_dtype_of(g_out), _p(g_y), _p(g_resid),
+                                                int(want_dbias), part.data_ptr(), part.numel() * 4, stream_ptr()),
+          "kvq_dropout_residual_ln_bwd_partial")
+    return g_y, g_resid, part
+
+
+def colsum_partial(x, cols=None):
+    """Per-workgroup partial column sums of a row-major 2-D tensor: part [rows, C] f32 (finish with reduce_batch())."""
+    N = x.shape[0]
+    C = x.shape[1] if cols is None else cols
+    l = lib()
+    part = torch.empty((l.kvq_colsum_partial_rows(N), C), dtype=torch.float32, device=x.device)
+    check(l.kvq_colsum_partial(x.data_ptr(), N, C, x.stride(0), io_dtype_of(x), part.data_ptr(), part.numel() * 4, stream_ptr()),
+          "kvq_colsum_partial")
+    return part
+
+
+def reduce_item(src, dst, count, cols, ld, scale=1.0, accumulate=False, src_offset=0):
+    """One entry of reduce_batch(): dst[c] (= | +=) scale * sum_{p<count} src.flat[src_offset + p*ld + c], c < cols."""
+    from ._ffi import ReduceItem
+    return ReduceItem(src.data_ptr() + src_offset * src.element_size(), dst.data_ptr(), int(count), int(cols), int(ld), float(scale),
+                      io_dtype_of(src), io_dtype_of(dst), int(accumulate))
+
+
+def reduce_batch(items):
+    """Run a list of reduce_item()s, KVQ_REDUCE_MAX_ITEMS per launch.  The caller keeps the source tensors alive until here."""
+    from ._ffi import ReduceItem, KVQ_REDUCE_MAX_ITEMS
+    l = lib()
+    st = stream_ptr()
+    for i in range(0, len(items), KVQ_REDUCE_MAX_ITEMS):
+        chunk = items[i:i + KVQ_REDUCE_MAX_ITEMS]
+        arr = (ReduceItem * len(chunk))(*chunk)
+        check(l.kvq_reduce_batch(arr, len(chunk), st), "kvq_reduce_batch")
+
+
 def sum_slabs(part, out):
     """out = part.sum(0) for a [S, ...] stack of split-K partial results (f32 accumulate)."""
     S = part.shape[0]

@@ -105,6 +105,53 @@ def test_sum_slabs(ops, dtype):
     torch.testing.assert_close(out.float(), part.float().sum(0).to(dtype).float(), rtol=1e-5, atol=1e-5)
 
 
+def test_reduce_batch_mixed_items(ops):
+    """One launch: split-K slab sums (bf16 and f32), LayerNorm partial finals with column offsets, a colsum final, accumulate."""
+    torch.manual_seed(6)
+    dev = "cuda"
+    slabs_b = torch.randn(16, 768, 768, device=dev).bfloat16(); out_b = torch.empty(768, 768, device=dev, dtype=torch.bfloat16)
+    slabs_f = torch.randn(3, 100, 44, device=dev); out_f = torch.ones(100, 44, device=dev)
+    x = torch.randn(8192, 2304, device=dev).bfloat16()
+    part_c = ops.colsum_partial(x); out_c = torch.empty(2304, device=dev, dtype=torch.bfloat16)
+    H = 768
+    part_ln = torch.randn(1024, 3 * H, device=dev); tgt = torch.zeros(3 * H + 8, device=dev, dtype=torch.bfloat16)
+    lone = torch.empty(H, device=dev)                       # f32 target, unaligned source column offset is fine in tree mode
+    odd = torch.randn(5, 1001, device=dev); out_odd = torch.empty(1001, device=dev)      # cols % 4 != 0 -> tree path
+    items = [ops.reduce_item(slabs_b, out_b, 16, 768 * 768, 768 * 768),
+             ops.reduce_item(slabs_f, out_f, 3, 4400, 4400, scale=0.5, accumulate=True),
+             ops.reduce_item(part_c, out_c, part_c.shape[0], 2304, 2304),
+             ops.reduce_item(part_ln, tgt[8:], 1024, 2 * H, 3 * H, src_offset=H),
+             ops.reduce_item(part_ln, lone, 1024, H, 3 * H),
+             ops.reduce_item(odd, out_odd, 5, 1001, 1001)]
+    ops.reduce_batch(items)
+    torch.testing.assert_close(out_b.float(), slabs_b.float().sum(0).bfloat16().float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out_f, 1 + 0.5 * slabs_f.sum(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out_c.float(), x.float().sum(0), rtol=1e-2, atol=0.5)
+    torch.testing.assert_close(tgt[8:8 + 2 * H].float(), part_ln[:, H:].sum(0), rtol=1e-2, atol=0.3)
+    assert torch.all(tgt[:8] == 0) and torch.all(tgt[8 + 2 * H:] == 0)
+    torch.testing.assert_close(lone, part_ln[:, :H].sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(out_odd, odd.sum(0), rtol=1e-5, atol=1e-5)
+    many = [ops.reduce_item(slabs_f, torch.empty(100, 44, device=dev), 3, 4400, 4400) for _ in range(37)]   # > 16 items: several launches
+    ops.reduce_batch(many)
+    from kvq import _ffi
+    arr = (_ffi.ReduceItem * 17)()
+    assert _ffi.lib().kvq_reduce_batch(arr, 17, None) != 0 and _ffi.lib().kvq_reduce_batch(arr, 1, None) != 0     # too many / null item
+
+
+def test_ln_bwd_partial_plus_reduce_equals_ln_bwd(ops):
+    torch.manual_seed(8)
+    N, H = 2048, 768
+    g = torch.randn(N, H, device="cuda").bfloat16(); y = torch.randn(N, H, device="cuda").bfloat16(); r = torch.randn(N, H, device="cuda").bfloat16()
+    gamma = torch.randn(H, device="cuda"); beta = torch.randn(H, device="cuda")
+    out, pre, mean, rstd = ops.ln_fwd(y, r, gamma, beta, 1e-12, 0.1, 3, 4)
+    flat = torch.zeros(3 * H, device="cuda", dtype=torch.bfloat16)
+    gy0, gr0 = ops.ln_bwd(g, pre, mean, rstd, gamma, 0.1, 3, 4, g_gamma=flat[H:2 * H], g_beta=flat[2 * H:], g_bias_prev=flat[:H])
+    gy1, gr1, part = ops.ln_bwd_partial(g, pre, mean, rstd, gamma, 0.1, 3, 4, want_dbias=True)
+    flat1 = torch.zeros_like(flat)
+    ops.reduce_batch([ops.reduce_item(part, flat1, part.shape[0], 3 * H, 3 * H)])
+    assert torch.equal(gy0, gy1) and torch.equal(gr0, gr1) and torch.equal(flat, flat1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gelu(ops, dtype):
     torch.manual_seed(0)
