@@ -208,6 +208,12 @@ int kvq_sum_slabs(const void* part, int S, int64_t n, int io_dtype, void* out, v
 /* BertIntermediate activation (:325-337), erf GELU.  n elements, n %% 4 == 0. */
 int kvq_gelu_fwd(const void* h, void* a, int64_t n, int io_dtype, void* stream);
 int kvq_gelu_bwd(const void* h, const void* g_a, void* g_h, int64_t n, int io_dtype, void* stream);
+/* kvq_gelu_bwd on a row-major [N, C] activation that also leaves bias_part [kvq_gelu_bwd_partial_rows(N)][C] f32 = partial
+ * column sums of g_h (as stored, i.e. after rounding to the io dtype): the bias gradient of the dense layer in front of
+ * the GELU (BertIntermediate, modeling_bert.py:298-310), finished by kvq_reduce_batch.  C %% 4 == 0. */
+int64_t kvq_gelu_bwd_partial_rows(int64_t N);
+int kvq_gelu_bwd_bias(const void* h, const void* g_a, void* g_h, int64_t N, int64_t C, int io_dtype, float* bias_part,
+                      size_t part_bytes, void* stream);
 
 /* BertSelfAttention / BertCrossAttention core (:111-204) for S_q, S_k <= 32 and head dim 64: softmax(q k^T * scale + mask) v
  * with dropout on the probabilities.  q [B*Sq, ldq], k/v [B*Sk, ldk/ldv], out [B*Sq, ldo]; head h lives at columns h*64..;
@@ -217,7 +223,11 @@ int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mas
                  int io_dtype, void* out, float* lse, void* stream);
 int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mask, const void* g_out, int B, int nh, int Sq,
                  int Sk, int dh, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed,
-                 uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v, void* stream);
+                 uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v, float* bias_part_q, float* bias_part_k,
+                 float* bias_part_v, int ldp_q, int ldp_kv, void* stream);
+/* bias_part_* (each may be NULL): per-batch column sums of g_q / g_k / g_v, [B][ldp_q] resp. [B][ldp_kv] f32, columns
+ * 0 .. nh*64 -- the partial rows of the q/k/v projection bias gradients (modeling_bert.py:83-85 biases), to be finished by
+ * kvq_reduce_batch over the B rows.  The MFMA kernels emit them on the way out; the other flavours run a column-sum pass. */
 
 /* bf16 attention flavour: 2 (default) = MFMA kernels (v_mfma_f32_32x32x16_bf16 for all five products), 1 = packed-dot
  * kernels (v_dot2c_f32_bf16); both round probabilities / dS to bf16 before P.V, dS.K, dS^T.Q, P^T.dO.  0 = convert-and-fma

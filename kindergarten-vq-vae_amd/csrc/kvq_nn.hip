@@ -218,12 +218,12 @@ constexpr int CS_ROWS = 128;   // rows per partial block
 // 1 KiB of f32 per row: fully coalesced), waves interleave rows, then the 4 waves are summed through LDS.
 template <int DT_IN>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ x, int64_t N, int64_t C,
-                                                              int64_t ld, float* __restrict__ part) {
+                                                              int64_t ld, float* __restrict__ part, int rows_per_block, int64_t ldpart) {
     __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * 4;
-    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
-    const int64_t r1 = r0 + CS_ROWS < N ? r0 + CS_ROWS : N;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (c0 < C) {
         const bool vec = (c0 + 4 <= C) && (ld % 4 == 0) &&
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restr
     __syncthreads();
     if (w == 0 && c0 < C) {
         const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        for (int u = 0; u < 4 && c0 + u < C; ++u) part[(size_t)blockIdx.y * C + c0 + u] = t[u];
+        for (int u = 0; u < 4 && c0 + u < C; ++u) part[(size_t)blockIdx.y * ldpart + c0 + u] = t[u];
     }
 }
 
@@ -399,6 +399,43 @@ __global__ __launch_bounds__(256) void gelu_kernel(const void* __restrict__ h, c
     }
 }
 
+// GELU backward that also leaves the column sums of g_h (the bias gradient of the dense layer in front of the GELU) as partial
+// rows: grid (ceil(C/1024), ceil(N/GB_ROWS)), each thread owns 4 columns and walks GB_ROWS rows with 4 loads in flight.
+constexpr int GB_ROWS = 32;
+template <int DT>
+__global__ __launch_bounds__(256) void gelu_bwd_bias_kernel(const void* __restrict__ h, const void* __restrict__ g_a,
+                                                             void* __restrict__ g_h, int64_t N, int64_t C, float* __restrict__ part) {
+    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * GB_ROWS;
+    const int64_t r1 = r0 + GB_ROWS < N ? r0 + GB_ROWS : N;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        f32x4 x[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { x[u] = IO<DT>::load4(h, (size_t)(r + u) * C + c); g[u] = IO<DT>::load4(g_a, (size_t)(r + u) * C + c); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 o;
+            o.x = g[u].x * gelu_grad_f(x[u].x); o.y = g[u].y * gelu_grad_f(x[u].y);
+            o.z = g[u].z * gelu_grad_f(x[u].z); o.w = g[u].w * gelu_grad_f(x[u].w);
+            IO<DT>::store4(g_h, (size_t)(r + u) * C + c, o);
+            o.x = IO<DT>::round(o.x); o.y = IO<DT>::round(o.y); o.z = IO<DT>::round(o.z); o.w = IO<DT>::round(o.w);
+            acc += o;                                  // sum what the weight-gradient GEMM will read
+        }
+    }
+    for (; r < r1; ++r) {
+        const f32x4 x = IO<DT>::load4(h, (size_t)r * C + c), g = IO<DT>::load4(g_a, (size_t)r * C + c);
+        f32x4 o;
+        o.x = g.x * gelu_grad_f(x.x); o.y = g.y * gelu_grad_f(x.y); o.z = g.z * gelu_grad_f(x.z); o.w = g.w * gelu_grad_f(x.w);
+        IO<DT>::store4(g_h, (size_t)r * C + c, o);
+        o.x = IO<DT>::round(o.x); o.y = IO<DT>::round(o.y); o.z = IO<DT>::round(o.z); o.w = IO<DT>::round(o.w);
+        acc += o;
+    }
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.y * C + c) = acc;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam, coupled L2 weight decay, optional amsgrad) on flat buffers:
 //   p32 (master, f32), g (bf16 or f32), m, v (f32) [, vmax], shadow (bf16 copy of p32 for the next forward)
@@ -456,6 +493,8 @@ struct AttnParams {
     // backward
     const void* g_out;
     void *g_q, *g_k, *g_v;
+    float *pb_q, *pb_k, *pb_v;   // optional per-batch column sums of g_q / g_k / g_v: [B][ldp_q] / [B][ldp_kv] f32 (bias-gradient partials)
+    int ldp_q, ldp_kv;
     int B, nh, Sq, Sk;
     int ldq, ldk, ldv, ldo;   // row strides in elements
     int causal;
@@ -1031,6 +1070,19 @@ __device__ __forceinline__ void store_ct(void* base, size_t row_off, int h, int 
         *reinterpret_cast<uint2*>(p + 8 * g) = w;
     }
 }
+// bias-gradient partial of one projection: sum_rows X[row][d] * w[row] for d = 32h + r, X from its pair-interleaved tile,
+// w (f32, one per row) broadcast from LDS.  Equals the column sum over this sentence of the gradient the kernel stores.
+__device__ __forceinline__ float weighted_colsum(const unsigned* Xt, const float* w, int r, int h) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int rp = 0; rp < 16; ++rp) {
+        const unsigned x = Xt[rp * AM_LDT + 32 * h + r];
+        const float2 c = *reinterpret_cast<const float2*>(w + 2 * rp);
+        a0 = __builtin_fmaf(__uint_as_float(x << 16), c.x, a0);
+        a1 = __builtin_fmaf(__uint_as_float(x & 0xffff0000u), c.y, a1);
+    }
+    return a0 + a1;
+}
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -1079,6 +1131,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
 __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned Kt[16 * AM_LDT], Qt[16 * AM_LDT], Gt[16 * AM_LDT];
     __shared__ __attribute__((aligned(16))) unsigned TD[AT_S * AM_LDX], TP[AT_S * AM_LDX];
+    __shared__ __attribute__((aligned(16))) float Wv[3 * AT_S];
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
     const bool kvalid = r < p.Sk, qvalid = r < p.Sq;
@@ -1148,6 +1201,28 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<0>(Gt, 32 * dt + r, h, st), tpf[st], o);
         if (kvalid) store_ct(p.g_v, ((size_t)b * p.Sk + r) * p.ldv + hd * AT_D, h, 32 * dt, o);
+    }
+    if (p.pb_q || p.pb_k || p.pb_v) {                       // wave-uniform
+        // column sums over this sentence of the three gradients = bias-gradient partials of the q / k / v projections:
+        //   sum_q dQ[q][d] = sum_key K[key][d] cs[key],  cs[key] = sum_q dS[q][key]     (from the transposed image, lane = key)
+        //   sum_k dK[k][d] = sum_q   Q[q][d]   rs[q],    rs[q]   = sum_key dS[q][key]   (lane-local)
+        //   sum_k dV[k][d] = sum_q  dO[q][d]   rp[q],    rp[q]   = sum_key P~[q][key]
+        float rs = 0.f, rp = 0.f, cs = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { rs += IO<KVQ_BF16>::round(ds[v]); rp += IO<KVQ_BF16>::round(s[v]); }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const unsigned w4[4] = {tdf[st].x, tdf[st].y, tdf[st].z, tdf[st].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cs += __uint_as_float(w4[u] << 16) + __uint_as_float(w4[u] & 0xffff0000u);
+        }
+        rs += __shfl_xor(rs, 32, WAVE); rp += __shfl_xor(rp, 32, WAVE); cs += __shfl_xor(cs, 32, WAVE);
+        if (h == 0) { Wv[r] = cs; Wv[32 + r] = rs; Wv[64 + r] = rp; }
+        __syncthreads();
+        const size_t col = (size_t)hd * AT_D + 32 * h + r;
+        if (p.pb_q) p.pb_q[(size_t)b * p.ldp_q + col] = weighted_colsum(Kt, Wv, r, h);
+        if (p.pb_k) p.pb_k[(size_t)b * p.ldp_kv + col] = weighted_colsum(Qt, Wv + 32, r, h);
+        if (p.pb_v) p.pb_v[(size_t)b * p.ldp_kv + col] = weighted_colsum(Gt, Wv + 64, r, h);
     }
 }
 
@@ -1263,8 +1338,8 @@ int kvq_colsum_partial(const void* x, int64_t N, int64_t C, int64_t ld, int in_d
     hipStream_t st = (hipStream_t)stream;
     const int64_t P = (N + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((unsigned)((C + 255) / 256), (unsigned)P);
-    DISPATCH_DT(in_dtype, hipLaunchKernelGGL(colsum_partial_kernel<KVQ_F32>, grid, dim3(256), 0, st, x, N, C, ld, (float*)part),
-                hipLaunchKernelGGL(colsum_partial_kernel<KVQ_BF16>, grid, dim3(256), 0, st, x, N, C, ld, (float*)part));
+    DISPATCH_DT(in_dtype, hipLaunchKernelGGL(colsum_partial_kernel<KVQ_F32>, grid, dim3(256), 0, st, x, N, C, ld, (float*)part, CS_ROWS, C),
+                hipLaunchKernelGGL(colsum_partial_kernel<KVQ_BF16>, grid, dim3(256), 0, st, x, N, C, ld, (float*)part, CS_ROWS, C));
     return check_launch("colsum_partial_kernel");
 }
 
@@ -1314,6 +1389,22 @@ int kvq_gelu_fwd(const void* h, void* a, int64_t n, int io_dtype, void* stream) 
     DISPATCH_DT(io_dtype, hipLaunchKernelGGL((gelu_kernel<KVQ_F32, false>), dim3(blocks), dim3(256), 0, st, h, nullptr, a, n4),
                 hipLaunchKernelGGL((gelu_kernel<KVQ_BF16, false>), dim3(blocks), dim3(256), 0, st, h, nullptr, a, n4));
     return check_launch("gelu_kernel");
+}
+
+int64_t kvq_gelu_bwd_partial_rows(int64_t N) { return (N + GB_ROWS - 1) / GB_ROWS; }
+
+int kvq_gelu_bwd_bias(const void* h, const void* g_a, void* g_h, int64_t N, int64_t C, int io_dtype, float* bias_part,
+                      size_t part_bytes, void* stream) {
+    KVQ_REQUIRE(h && g_a && g_h && bias_part && N > 0 && C > 0 && C % 4 == 0, "kvq_gelu_bwd_bias: bad argument (C %% 4 == 0 required)");
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
+    const int64_t P = (N + GB_ROWS - 1) / GB_ROWS;
+    if (part_bytes < (size_t)P * C * sizeof(float)) return fail(KVQ_E_WORKSPACE, "kvq_gelu_bwd_bias: partial buffer %zu < %zu", part_bytes, (size_t)P * C * sizeof(float));
+    KVQ_REQUIRE(P <= 65535, "kvq_gelu_bwd_bias: N too large");
+    dim3 grid((unsigned)((C + 1023) / 1024), (unsigned)P);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(gelu_bwd_bias_kernel<KVQ_F32>, grid, dim3(256), 0, st, h, g_a, g_h, N, C, bias_part),
+                hipLaunchKernelGGL(gelu_bwd_bias_kernel<KVQ_BF16>, grid, dim3(256), 0, st, h, g_a, g_h, N, C, bias_part));
+    return check_launch("gelu_bwd_bias_kernel");
 }
 
 int kvq_gelu_bwd(const void* h, const void* g_a, void* g_h, int64_t n, int io_dtype, void* stream) {
@@ -1378,24 +1469,42 @@ int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mas
     return check_launch("attn_fwd_kernel");
 }
 
+// per-batch column sums of a [B*S, ld] gradient (head columns 0 .. nh*64): the fallback of the kernels that do not emit them
+static int attn_bias_partials(const void* g, int B, int S, int C, int ld, int io_dtype, float* part, int ldp, hipStream_t st) {
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)B);
+    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(colsum_partial_kernel<KVQ_F32>, grid, dim3(256), 0, st, g, (int64_t)B * S, C, ld, part, S, ldp),
+                hipLaunchKernelGGL(colsum_partial_kernel<KVQ_BF16>, grid, dim3(256), 0, st, g, (int64_t)B * S, C, ld, part, S, ldp));
+    return check_launch("colsum_partial_kernel");
+}
+
 int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mask, const void* g_out, int B, int nh, int Sq,
                  int Sk, int dh, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed,
-                 uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v, void* stream) {
+                 uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v, float* bias_part_q, float* bias_part_k,
+                 float* bias_part_v, int ldp_q, int ldp_kv, void* stream) {
     KVQ_REQUIRE(q && k && v && g_out && g_q && g_k && g_v, "kvq_attn_bwd: null pointer argument");
     int rc = attn_check(B, nh, Sq, Sk, dh, io_dtype);
     if (rc) return rc;
     AttnParams p = {};
     p.q = q; p.k = k; p.v = v; p.mask = mask; p.g_out = g_out; p.g_q = g_q; p.g_k = g_k; p.g_v = g_v;
+    KVQ_REQUIRE((!bias_part_q || ldp_q >= nh * AT_D) && ((!bias_part_k && !bias_part_v) || ldp_kv >= nh * AT_D),
+                "kvq_attn_bwd: bias partial row strides must cover nh*64 columns");
+    p.pb_q = bias_part_q; p.pb_k = bias_part_k; p.pb_v = bias_part_v; p.ldp_q = ldp_q; p.ldp_kv = ldp_kv;
     p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.causal = causal;
     p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.site = site;
     hipStream_t st = (hipStream_t)stream;
     const bool al = (ldq % 8 == 0) && (ldk % 8 == 0) && (ldv % 8 == 0) && (ldo % 8 == 0) &&
                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)g_out | (uintptr_t)g_q | (uintptr_t)g_k | (uintptr_t)g_v) % 16 == 0);
+    bool emits_partials = false;
     if (io_dtype == KVQ_F32) hipLaunchKernelGGL(attn_bwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
-    else if (al && g_attn_variant == 2) hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else if (al && g_attn_variant == 2) { hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p); emits_partials = true; }
     else if (al && g_attn_variant == 1) hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
-    return check_launch("attn_bwd_kernel");
+    rc = check_launch("attn_bwd_kernel");
+    if (rc || emits_partials) return rc;
+    if (bias_part_q) { rc = attn_bias_partials(g_q, B, Sq, nh * AT_D, ldq, io_dtype, bias_part_q, ldp_q, st); if (rc) return rc; }
+    if (bias_part_k) { rc = attn_bias_partials(g_k, B, Sk, nh * AT_D, ldk, io_dtype, bias_part_k, ldp_kv, st); if (rc) return rc; }
+    if (bias_part_v) { rc = attn_bias_partials(g_v, B, Sk, nh * AT_D, ldv, io_dtype, bias_part_v, ldp_kv, st); if (rc) return rc; }
+    return KVQ_OK;
 }
 
 }  // extern "C"

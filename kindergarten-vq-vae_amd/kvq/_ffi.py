@@ -58,10 +58,12 @@ SIGNATURES = {
     "kvq_colsum_partial": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _sz, _vp]),
     "kvq_gelu_fwd": (_int, [_vp, _vp, _i64, _int, _vp]),
     "kvq_gelu_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    "kvq_gelu_bwd_partial_rows": (_i64, [_i64]),
+    "kvq_gelu_bwd_bias": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _vp, _sz, _vp]),
     "kvq_attn_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32,
                             C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp]),
     "kvq_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32,
-                            C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp]),
+                            C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
     "kvq_gemm_nt_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_set_stages": (_int, [_int]),
     "kvq_gemm_nt_bf16_gelu": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),

@@ -398,18 +398,31 @@ class TrainEngine:
                                  g_beta=fl.g(pre + "ln.b") if tr[pre + "ln.b"] else None,
                                  g_bias_prev=fl.g(pre + "o.b") if tr[pre + "o.b"] else None)
         g_ctx = self._linear_bwd(g_ao, ctx, [pre + "o.w"], [pre + "o.b"], bias_done=True)
+        # the attention backward kernel also emits the per-sentence column sums of g_q / g_k / g_v: the q/k/v bias gradients
+        # are then one deferred reduction over B rows instead of a second pass over the [N, 3H] gradient
         g_qkv = torch.empty_like(qkv)
+        want_b = tr[pre + "q.b"]
         if kv_src is None:
             q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+            pb = torch.empty((B, 3 * H), dtype=torch.float32, device=self.dev) if want_b else None
             nnops.attn_bwd(q, k, v, mask, g_ctx, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a,
-                           g_qkv[:, :H], g_qkv[:, H:2 * H], g_qkv[:, 2 * H:])
-            self._linear_bwd(g_qkv, x, [pre + "q.w", pre + "k.w", pre + "v.w"], [pre + "q.b", pre + "k.b", pre + "v.b"], gx_accum=g_x)
+                           g_qkv[:, :H], g_qkv[:, H:2 * H], g_qkv[:, 2 * H:],
+                           *((pb[:, :H], pb[:, H:2 * H], pb[:, 2 * H:]) if want_b else ()))
+            if want_b:
+                self._defer(pb, fl.fused([pre + "q.b", pre + "k.b", pre + "v.b"], fl.grad), B, 3 * H, 3 * H)
+            self._linear_bwd(g_qkv, x, [pre + "q.w", pre + "k.w", pre + "v.w"], [pre + "q.b", pre + "k.b", pre + "v.b"], gx_accum=g_x,
+                             bias_done=want_b)
         else:
             g_kv = torch.empty_like(kvbuf)
+            pbq = torch.empty((B, H), dtype=torch.float32, device=self.dev) if want_b else None
+            pbkv = torch.empty((B, 2 * H), dtype=torch.float32, device=self.dev) if want_b else None
             nnops.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], mask, g_ctx, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a,
-                           g_qkv, g_kv[:, :H], g_kv[:, H:])
-            self._linear_bwd(g_qkv, x, [pre + "q.w"], [pre + "q.b"], gx_accum=g_x)
-            self._linear_bwd(g_kv, kv_src, [pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"], gx_accum=g_kv_src)
+                           g_qkv, g_kv[:, :H], g_kv[:, H:], *((pbq, pbkv[:, :H], pbkv[:, H:]) if want_b else ()))
+            if want_b:
+                self._defer(pbq, fl.g(pre + "q.b"), B, H, H)
+                self._defer(pbkv, fl.fused([pre + "k.b", pre + "v.b"], fl.grad), B, 2 * H, 2 * H)
+            self._linear_bwd(g_qkv, x, [pre + "q.w"], [pre + "q.b"], gx_accum=g_x, bias_done=want_b)
+            self._linear_bwd(g_kv, kv_src, [pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"], gx_accum=g_kv_src, bias_done=want_b)
         return g_x
 
     def _ffn_fwd(self, pre, x, cfg, training):
@@ -432,8 +445,13 @@ class TrainEngine:
                                 g_beta=fl.g(pre + "ln2.b") if tr[pre + "ln2.b"] else None,
                                 g_bias_prev=fl.g(pre + "f2.b") if tr[pre + "f2.b"] else None)
         g_a = self._linear_bwd(g_f, a, [pre + "f2.w"], [pre + "f2.b"], bias_done=True)
-        g_h = nnops.gelu_bwd(h, g_a, out=g_a)
-        self._linear_bwd(g_h, x, [pre + "f1.w"], [pre + "f1.b"], gx_accum=g_x)
+        if tr[pre + "f1.b"] and h.is_contiguous() and h.shape[1] % 4 == 0:
+            g_h, pb = nnops.gelu_bwd_bias(h, g_a, out=g_a)           # bias gradient partials come out of the same pass
+            self._defer(pb, fl.g(pre + "f1.b"), pb.shape[0], pb.shape[1], pb.shape[1])
+            self._linear_bwd(g_h, x, [pre + "f1.w"], [pre + "f1.b"], gx_accum=g_x, bias_done=True)
+        else:
+            g_h = nnops.gelu_bwd(h, g_a, out=g_a)
+            self._linear_bwd(g_h, x, [pre + "f1.w"], [pre + "f1.b"], gx_accum=g_x)
         return g_x
 
     # ------------------------------------------------------------------------------------------------------------
@@ -558,8 +576,13 @@ class TrainEngine:
         g_ta, _ = self._ln_bwd(g_hN, hpre, hmean, hrstd, fl.w32("head.ln.w"), 0.0, 0, 0,
                                g_gamma=fl.g("head.ln.w") if tr["head.ln.w"] else None,
                                g_beta=fl.g("head.ln.b") if tr["head.ln.b"] else None, need_g_resid=False)
-        g_t = nnops.gelu_bwd(t, g_ta, out=g_ta)
-        g_y = self._linear_bwd(g_t, y, ["head.t.w"], ["head.t.b"])
+        if tr["head.t.b"] and t.is_contiguous():
+            g_t, pb = nnops.gelu_bwd_bias(t, g_ta, out=g_ta)
+            self._defer(pb, fl.g("head.t.b"), pb.shape[0], pb.shape[1], pb.shape[1])
+            g_y = self._linear_bwd(g_t, y, ["head.t.w"], ["head.t.b"], bias_done=True)
+        else:
+            g_t = nnops.gelu_bwd(t, g_ta, out=g_ta)
+            g_y = self._linear_bwd(g_t, y, ["head.t.w"], ["head.t.b"])
         self._grads_done_down_to("head.t.w")
         g_enc = torch.zeros_like(enc_out)
         for i in reversed(range(self.n_dec_layers)):

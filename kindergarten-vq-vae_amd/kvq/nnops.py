@@ -118,6 +118,17 @@ def gelu_bwd(h, g_a, out=None):
     return g_h
 
 
+def gelu_bwd_bias(h, g_a, out=None):
+    """(g_h, part): gelu_bwd plus part [rows, C] f32 partial column sums of g_h (bias gradient partials for reduce_batch())."""
+    N, Cc = h.shape
+    g_h = torch.empty_like(h) if out is None else out
+    l = lib()
+    part = torch.empty((l.kvq_gelu_bwd_partial_rows(N), Cc), dtype=torch.float32, device=h.device)
+    check(l.kvq_gelu_bwd_bias(h.data_ptr(), g_a.data_ptr(), g_h.data_ptr(), N, Cc, io_dtype_of(h), part.data_ptr(), part.numel() * 4,
+                              stream_ptr()), "kvq_gelu_bwd_bias")
+    return g_h, part
+
+
 def attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_drop=0.0, seed=0, site=0, out=None):
     """q [B*Sq, >=nh*64] (any row stride), k, v [B*Sk, ...]; returns (ctx [B*Sq, nh*64], lse [B, nh, Sq])."""
     require_gpu(q, k, v)
@@ -130,13 +141,22 @@ def attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_drop=0.0, seed=0, site=0, o
     return ctx, lse
 
 
-def attn_bwd(q, k, v, mask, g_ctx, B, nh, Sq, Sk, causal, p_drop, seed, site, g_q, g_k, g_v):
-    """Writes g_q / g_k / g_v (same layouts / row strides as q / k / v)."""
+def attn_bwd(q, k, v, mask, g_ctx, B, nh, Sq, Sk, causal, p_drop, seed, site, g_q, g_k, g_v, bias_part_q=None, bias_part_k=None,
+             bias_part_v=None):
+    """Writes g_q / g_k / g_v (same layouts / row strides as q / k / v).  bias_part_* (f32 2-D views with B rows, row stride
+    free, k and v sharing one) receive the per-batch column sums of g_q / g_k / g_v = partial rows of the projection-bias gradients."""
     dh = 64
     assert g_q.stride(0) == q.stride(0) and g_k.stride(0) == k.stride(0) and g_v.stride(0) == v.stride(0)
+    ldp_q = bias_part_q.stride(0) if bias_part_q is not None else 0
+    kv_ref = bias_part_k if bias_part_k is not None else bias_part_v
+    ldp_kv = kv_ref.stride(0) if kv_ref is not None else 0
+    for t in (bias_part_q, bias_part_k, bias_part_v):
+        assert t is None or (t.dtype == torch.float32 and t.shape[0] == B and t.shape[1] >= nh * dh and t.stride(1) == 1)
+    assert bias_part_k is None or bias_part_v is None or bias_part_k.stride(0) == bias_part_v.stride(0)
     check(lib().kvq_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(mask), g_ctx.data_ptr(), B, nh, Sq, Sk, dh, q.stride(0),
                              k.stride(0), v.stride(0), g_ctx.stride(0), int(causal), 1.0 / 8.0, float(p_drop), int(seed), int(site),
-                             io_dtype_of(q), g_q.data_ptr(), g_k.data_ptr(), g_v.data_ptr(), stream_ptr()), "kvq_attn_bwd")
+                             io_dtype_of(q), g_q.data_ptr(), g_k.data_ptr(), g_v.data_ptr(), _p(bias_part_q), _p(bias_part_k),
+                             _p(bias_part_v), int(ldp_q), int(ldp_kv), stream_ptr()), "kvq_attn_bwd")
 
 
 def adam_step(p32, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, vmax=None, shadow=None, grad_scale=1.0):

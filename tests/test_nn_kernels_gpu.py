@@ -162,6 +162,9 @@ def test_gelu(ops, dtype):
     ref.backward(g.float())
     torch.testing.assert_close(ops.gelu_fwd(h).float(), ref.detach(), **_tol(dtype))
     torch.testing.assert_close(ops.gelu_bwd(h, g).float(), hr.grad, **_tol(dtype))
+    g_h, part = ops.gelu_bwd_bias(h, g)                      # same values + column-sum partials of what was stored
+    assert torch.equal(g_h, ops.gelu_bwd(h, g)) and part.shape == (32, 3072)
+    torch.testing.assert_close(part.sum(0), g_h.float().sum(0), rtol=1e-4, atol=1e-2)
 
 
 def _ref_attention(q, k, v, mask, causal, keep=None, p=0.0):
@@ -215,7 +218,14 @@ def test_attention_fwd_bwd(ops, B, nh, Sq, Sk, causal, masked, dtype):
         gq, gk, gv = gbuf_q[:, :H], gbuf_q[:, H:2 * H], gbuf_q[:, 2 * H:]
     else:
         gq, gk, gv = gbuf_q[:, :H], gbuf_kv[:, :H], gbuf_kv[:, H:]
-    ops.attn_bwd(q, k, v, mask, g, B, nh, Sq, Sk, causal, 0.0, 0, 0, gq, gk, gv)
+    pbq = torch.full((B, H + 8), 7.0, device="cuda"); pbkv = torch.full((B, 2 * H), 7.0, device="cuda")
+    ops.attn_bwd(q, k, v, mask, g, B, nh, Sq, Sk, causal, 0.0, 0, 0, gq, gk, gv, pbq[:, :H], pbkv[:, :H], pbkv[:, H:])
+    # per-sentence column sums of the stored gradients (the q/k/v bias-gradient partial rows)
+    bt = dict(rtol=1e-2, atol=5e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(pbq[:, :H], gq.float().reshape(B, Sq, H).sum(1), **bt)
+    torch.testing.assert_close(pbkv[:, :H], gk.float().reshape(B, Sk, H).sum(1), **bt)
+    torch.testing.assert_close(pbkv[:, H:], gv.float().reshape(B, Sk, H).sum(1), **bt)
+    assert torch.all(pbq[:, H:] == 7.0)
     unh = lambda t, S: t.transpose(1, 2).reshape(B * S, H)
     t = _tol(dtype)
     torch.testing.assert_close(gq.float(), unh(qr.grad, Sq), **t)

@@ -19,4 +19,7 @@ for var in (0, 1, 2):
     _ffi.lib().kvq_attn_set_variant(var)
     f = t(lambda: nnops.attn_fwd(q, k, v, mask, B, nh, S, S, True, 0.1, 1, 2))
     b = t(lambda: nnops.attn_bwd(q, k, v, mask, g, B, nh, S, S, True, 0.1, 1, 2, gq[:, :H], gq[:, H:2*H], gq[:, 2*H:]))
-    print(f"variant {var}: fwd {f:.1f} us  bwd {b:.1f} us")
+    pb = torch.empty(B, 3 * H, device="cuda")
+    bp = t(lambda: nnops.attn_bwd(q, k, v, mask, g, B, nh, S, S, True, 0.1, 1, 2, gq[:, :H], gq[:, H:2*H], gq[:, 2*H:],
+                                  pb[:, :H], pb[:, H:2*H], pb[:, 2*H:]))
+    print(f"variant {var}: fwd {f:.1f} us  bwd {b:.1f} us  bwd + bias partials {bp:.1f} us")
