@@ -14,6 +14,7 @@
 #include <math.h>
 
 #include "kvq_common.h"
+#include <type_traits>
 
 namespace kvq {
 
@@ -129,6 +130,9 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
                                                         void* __restrict__ g_y, void* __restrict__ g_resid,
                                                         float* __restrict__ part_dgamma, int want_dbias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][3][H]
+    constexpr int RW = LNB_ROWS / 4;                              // rows per wave
+    constexpr int RF = PER <= 4 ? RW : 1;                         // ... of which RF are in flight at once (register budget)
+    typedef typename std::conditional<(PER > 8), unsigned long long, unsigned>::type KeepBits;   // 4 bits per chunk
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nchunk = H >> 2;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
@@ -136,51 +140,88 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         dg[t] = 0.f; db[t] = 0.f; dy[t] = 0.f;
-        const int c = lane + WAVE * t;
-        f32x4 one = {0.f, 0.f, 0.f, 0.f};
-        gm[t] = c < nchunk ? *reinterpret_cast<const f32x4*>(gamma + 4 * c) : one;
+        const int c = lane + WAVE * t < nchunk ? lane + WAVE * t : nchunk - 1;
+        gm[t] = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
     }
-    for (int r = 0; r < LNB_ROWS / 4; ++r) {
-        const int64_t row = (int64_t)blockIdx.x * LNB_ROWS + w * (LNB_ROWS / 4) + r;
-        if (row >= N) break;
-        const float mu = mean[row], rs = rstd[row];
-        f32x4 gg[PER], xh[PER];
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int c = lane + WAVE * t;
-            f32x4 tt = {0.f, 0.f, 0.f, 0.f}, x = {0.f, 0.f, 0.f, 0.f};
-            if (c < nchunk) {
+    for (int rb = 0; rb < RW; rb += RF) {
+        const int64_t row0 = (int64_t)blockIdx.x * LNB_ROWS + w * RW + rb;
+        if (row0 >= N) break;                                     // wave-uniform
+        // 1. every load of these rows goes out first (rows past N are clamped and weighted 0: no branch around a load)
+        f32x4 go[RF][PER], x[RF][PER];
+        float mu[RF], rs[RF], live[RF];
+#pragma unroll
+        for (int r = 0; r < RF; ++r) {
+            const int64_t row = row0 + r < N ? row0 + r : N - 1;
+            live[r] = row0 + r < N ? 1.0f : 0.0f;
+            mu[r] = mean[row]; rs[r] = rstd[row];
+#pragma unroll
+            for (int t = 0; t < PER; ++t) {
+                const int c = lane + WAVE * t < nchunk ? lane + WAVE * t : nchunk - 1;
                 const size_t off = (size_t)row * H + 4 * c;
-                const f32x4 go = IO<DT>::load4(g_out, off);
-                x = (IO<DT>::load4(pre, off) - mu) * rs;
-                tt = go * gm[t];
-                dg[t] += go * x;
-                db[t] += go;
-                s1 += (tt.x + tt.y) + (tt.z + tt.w);
-                s2 += (tt.x * x.x + tt.y * x.y) + (tt.z * x.z + tt.w * x.w);
+                go[r][t] = IO<DT>::load4(g_out, off);
+                x[r][t] = IO<DT>::load4(pre, off);
             }
-            gg[t] = tt; xh[t] = x;
         }
-        s1 = wave_sum_f32(s1) / (float)H;
-        s2 = wave_sum_f32(s2) / (float)H;
+        // 2. the dropout keep bits do not depend on the loads: Philox runs while they are in flight
+        KeepBits keepbits[RF];
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int c = lane + WAVE * t;
-            if (c < nchunk) {
-                const size_t off = (size_t)row * H + 4 * c;
-                f32x4 gp = (gg[t] - s1 - xh[t] * s2) * rs;
-                if (g_resid) IO<DT>::store4(g_resid, off, gp);
-                if (g_y) {
-                    if (p_drop > 0.f) {
-                        const U4 b = drop_bits(seed, site, (unsigned long long)row * nchunk + c);
-                        gp.x *= keep_scale(b.x, thresh, inv_keep); gp.y *= keep_scale(b.y, thresh, inv_keep);
-                        gp.z *= keep_scale(b.z, thresh, inv_keep); gp.w *= keep_scale(b.w, thresh, inv_keep);
+        for (int r = 0; r < RF; ++r) {
+            keepbits[r] = ~(KeepBits)0;
+            if (g_y && p_drop > 0.f) {
+                KeepBits kb = 0;
+#pragma unroll
+                for (int t = 0; t < PER; ++t) {
+                    const int c = lane + WAVE * t;
+                    const U4 b = drop_bits(seed, site, (unsigned long long)(row0 + r) * nchunk + c);
+                    kb |= (KeepBits)((b.x >= thresh ? 1u : 0u) | (b.y >= thresh ? 2u : 0u) | (b.z >= thresh ? 4u : 0u) | (b.w >= thresh ? 8u : 0u)) << (4 * t);
+                }
+                keepbits[r] = kb;
+            }
+        }
+        // 3. row statistics of all rows in flight, then their outputs
+        float s1[RF], s2[RF];
+#pragma unroll
+        for (int r = 0; r < RF; ++r) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < PER; ++t) {
+                const float m = (lane + WAVE * t < nchunk) ? live[r] : 0.0f;
+                const f32x4 g = go[r][t] * m;
+                const f32x4 xh = (x[r][t] - mu[r]) * rs[r];
+                const f32x4 tt = g * gm[t];
+                dg[t] += g * xh;
+                db[t] += g;
+                a1 += (tt.x + tt.y) + (tt.z + tt.w);
+                a2 += (tt.x * xh.x + tt.y * xh.y) + (tt.z * xh.z + tt.w * xh.w);
+                go[r][t] = tt; x[r][t] = xh;
+            }
+            s1[r] = a1; s2[r] = a2;
+        }
+#pragma unroll
+        for (int r = 0; r < RF; ++r) {
+            s1[r] = wave_sum_f32(s1[r]) / (float)H;
+            s2[r] = wave_sum_f32(s2[r]) / (float)H;
+        }
+#pragma unroll
+        for (int r = 0; r < RF; ++r) {
+            if (row0 + r >= N) break;                   // wave-uniform; only stores below
+#pragma unroll
+            for (int t = 0; t < PER; ++t) {
+                const int c = lane + WAVE * t;
+                if (c < nchunk) {
+                    const size_t off = (size_t)(row0 + r) * H + 4 * c;
+                    f32x4 gp = (go[r][t] - s1[r] - x[r][t] * s2[r]) * rs[r];
+                    if (g_resid) IO<DT>::store4(g_resid, off, gp);
+                    if (g_y) {
+                        const unsigned kb = (unsigned)(keepbits[r] >> (4 * t));
+                        gp.x *= (kb & 1u) ? inv_keep : 0.f; gp.y *= (kb & 2u) ? inv_keep : 0.f;
+                        gp.z *= (kb & 4u) ? inv_keep : 0.f; gp.w *= (kb & 8u) ? inv_keep : 0.f;
+                        IO<DT>::store4(g_y, off, gp);
+                        // what the consumer of g_y reads back is the STORED (possibly bf16-rounded) value
+                        dy[t].x += IO<DT>::round(gp.x); dy[t].y += IO<DT>::round(gp.y);
+                        dy[t].z += IO<DT>::round(gp.z); dy[t].w += IO<DT>::round(gp.w);
                     }
-                    IO<DT>::store4(g_y, off, gp);
-                    // what the consumer of g_y reads back is the STORED (possibly bf16-rounded) value
-                    dy[t].x += IO<DT>::round(gp.x); dy[t].y += IO<DT>::round(gp.y);
-                    dy[t].z += IO<DT>::round(gp.z); dy[t].w += IO<DT>::round(gp.w);
                 }
             }
         }
@@ -1250,7 +1291,8 @@ int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* g
 #define LAUNCH_LN_FWD(DTV, PERV)                                                                                          \
     hipLaunchKernelGGL((drln_fwd_kernel<DTV, PERV>), grid, dim3(256), 0, st, y, resid, gamma, beta, N, H, eps, p_drop, th, \
                        (unsigned long long)seed, site, out, pre, mean, rstd)
-    if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 4), LAUNCH_LN_FWD(KVQ_BF16, 4)); }
+    if (H <= 768) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 3), LAUNCH_LN_FWD(KVQ_BF16, 3)); }
+    else if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 4), LAUNCH_LN_FWD(KVQ_BF16, 4)); }
     else { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 16), LAUNCH_LN_FWD(KVQ_BF16, 16)); }
 #undef LAUNCH_LN_FWD
     return check_launch("drln_fwd_kernel");
@@ -1289,7 +1331,8 @@ int kvq_dropout_residual_ln_bwd_partial(const void* g_out, const void* pre, cons
 #define LAUNCH_LN_BWD(DTV, PERV)                                                                                             \
     hipLaunchKernelGGL((drln_bwd_kernel<DTV, PERV>), dim3((unsigned)blocks), dim3(256), lds, st, g_out, pre, mean, rstd, gamma, \
                        N, H, p_drop, th, (unsigned long long)seed, site, g_y, g_resid, pdg, want_dbias ? 1 : 0)
-    if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 4), LAUNCH_LN_BWD(KVQ_BF16, 4)); }
+    if (H <= 768) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 3), LAUNCH_LN_BWD(KVQ_BF16, 3)); }
+    else if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 4), LAUNCH_LN_BWD(KVQ_BF16, 4)); }
     else { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 16), LAUNCH_LN_BWD(KVQ_BF16, 16)); }
 #undef LAUNCH_LN_BWD
     return check_launch("drln_bwd_kernel");
