@@ -210,7 +210,7 @@ int kvq_gelu_fwd(const void* h, void* a, int64_t n, int io_dtype, void* stream);
 int kvq_gelu_bwd(const void* h, const void* g_a, void* g_h, int64_t n, int io_dtype, void* stream);
 /* kvq_gelu_bwd on a row-major [N, C] activation that also leaves bias_part [kvq_gelu_bwd_partial_rows(N)][C] f32 = partial
  * column sums of g_h (as stored, i.e. after rounding to the io dtype): the bias gradient of the dense layer in front of
- * the GELU (BertIntermediate, modeling_bert.py:298-310), finished by kvq_reduce_batch.  C %% 4 == 0. */
+ * the GELU (BertIntermediate, modeling_bert.py:298-310), finished by kvq_reduce_batch.  C %% 8 == 0, 16-byte aligned buffers. */
 int64_t kvq_gelu_bwd_partial_rows(int64_t N);
 int kvq_gelu_bwd_bias(const void* h, const void* g_a, void* g_h, int64_t N, int64_t C, int io_dtype, float* bias_part,
                       size_t part_bytes, void* stream);

@@ -38,6 +38,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float x) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
+// 8 consecutive elements: HBM-bound kernels move 16 bytes per lane and instruction (8-byte accesses run at 0.54-0.70x the
+// 16-byte rate on MI355X, MI355X_MICROARCH.md "sc1 / nt loads" row), i.e. 8 bf16 or 2 x 4 f32
+struct f32x8 {
+    f32x4 lo, hi;
+};
+
 template <int DT>
 struct IO;
 
@@ -57,6 +63,15 @@ struct IO<KVQ_F32> {
     }
     __device__ static __forceinline__ void store1(void* base, size_t off, float v) {
         reinterpret_cast<float*>(base)[off] = v;
+    }
+    __device__ static __forceinline__ f32x8 load8(const void* base, size_t off) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+        f32x8 v = {p[0], p[1]};
+        return v;
+    }
+    __device__ static __forceinline__ void store8(void* base, size_t off, const f32x8& v) {
+        f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off);
+        p[0] = v.lo; p[1] = v.hi;
     }
     // value the consumer of a stored element will read back
     __device__ static __forceinline__ float round(float v) { return v; }
@@ -80,6 +95,23 @@ struct IO<KVQ_BF16> {
     }
     __device__ static __forceinline__ void store1(void* base, size_t off, float v) {
         reinterpret_cast<unsigned short*>(base)[off] = f32_to_bf16(v);
+    }
+    // off % 8 == 0 and a 16-byte aligned base
+    __device__ static __forceinline__ f32x8 load8(const void* base, size_t off) {
+        const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + off);
+        f32x8 v;
+        v.lo.x = __uint_as_float(r.x << 16); v.lo.y = __uint_as_float(r.x & 0xffff0000u);
+        v.lo.z = __uint_as_float(r.y << 16); v.lo.w = __uint_as_float(r.y & 0xffff0000u);
+        v.hi.x = __uint_as_float(r.z << 16); v.hi.y = __uint_as_float(r.z & 0xffff0000u);
+        v.hi.z = __uint_as_float(r.w << 16); v.hi.w = __uint_as_float(r.w & 0xffff0000u);
+        return v;
+    }
+    __device__ static __forceinline__ void store8(void* base, size_t off, const f32x8& v) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        const bf2 a = {(__bf16)v.lo.x, (__bf16)v.lo.y}, b = {(__bf16)v.lo.z, (__bf16)v.lo.w};
+        const bf2 c = {(__bf16)v.hi.x, (__bf16)v.hi.y}, d = {(__bf16)v.hi.z, (__bf16)v.hi.w};
+        uint4 r = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)};
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(base) + off) = r;
     }
     __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 };

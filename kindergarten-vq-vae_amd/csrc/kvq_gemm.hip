@@ -51,7 +51,7 @@ constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2;
 // erf to ~1.2e-7 absolute (Abramowitz & Stegun 7.1.26): plenty under bf16 output rounding, ~12 VALU ops
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float r = 1.0f - poly * __expf(-ax * ax);
     return copysignf(r, x);

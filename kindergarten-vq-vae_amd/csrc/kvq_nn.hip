@@ -356,8 +356,16 @@ __device__ __forceinline__ void reduce_slab_block(const kvq_reduce_item& d, int 
     for (int u = 0; u < 2; ++u) {
         const int64_t c = c0 + 4096 * u;
         if (c < d.cols) {
-            f32x4 a = IO<DT_SRC>::load4(d.src, c);
-            for (int64_t p = 1; p < d.count; ++p) a += IO<DT_SRC>::load4(d.src, (size_t)p * d.ld + c);
+            f32x4 a = IO<DT_SRC>::load4(d.src, c), a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+            int64_t p = 1;
+            for (; p + 4 <= d.count; p += 4) {         // four slabs in flight; the grouping is fixed, so the sum stays deterministic
+                a += IO<DT_SRC>::load4(d.src, (size_t)p * d.ld + c);
+                a1 += IO<DT_SRC>::load4(d.src, (size_t)(p + 1) * d.ld + c);
+                a2 += IO<DT_SRC>::load4(d.src, (size_t)(p + 2) * d.ld + c);
+                a3 += IO<DT_SRC>::load4(d.src, (size_t)(p + 3) * d.ld + c);
+            }
+            for (; p < d.count; ++p) a += IO<DT_SRC>::load4(d.src, (size_t)p * d.ld + c);
+            a = (a + a1) + (a2 + a3);
             a *= d.scale;
             if (d.accumulate) a += IO<DT_DST>::load4(d.dst, c);
             IO<DT_DST>::store4(d.dst, c, a);
@@ -422,59 +430,105 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// bf16 io: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result) -- libm's erff
+// makes these kernels VALU-bound (~40 instructions per element) instead of HBM-bound.  exp(-x^2/2) is shared between the
+// erf tail and the Gaussian density of the derivative.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);      // v_rcp_f32 (1 ulp); __frcp_rn expands to a 12-instruction IEEE division
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    e = __expf(-z * z);                                   // = exp(-x^2 / 2)
+    const float half_tail = 0.5f * poly * e;              // 0.5 * erfc(|x| / sqrt 2)
+    cdf = x >= 0.f ? 1.0f - half_tail : half_tail;
+}
+template <int DT> __device__ __forceinline__ float gelu_v(float x) {
+    if (DT == KVQ_F32) return gelu_f(x);
+    float cdf, e;
+    gelu_parts_fast(x, cdf, e);
+    return x * cdf;
+}
+template <int DT> __device__ __forceinline__ float gelu_grad_v(float x) {
+    if (DT == KVQ_F32) return gelu_grad_f(x);
+    float cdf, e;
+    gelu_parts_fast(x, cdf, e);
+    return cdf + x * 0.39894228040143268f * e;
+}
 
 template <int DT, bool BWD>
+__device__ __forceinline__ f32x4 gelu_apply4(const f32x4& x, const f32x4& g) {
+    f32x4 o;
+    if (BWD) {
+        o.x = g.x * gelu_grad_v<DT>(x.x); o.y = g.y * gelu_grad_v<DT>(x.y);
+        o.z = g.z * gelu_grad_v<DT>(x.z); o.w = g.w * gelu_grad_v<DT>(x.w);
+    } else {
+        o.x = gelu_v<DT>(x.x); o.y = gelu_v<DT>(x.y); o.z = gelu_v<DT>(x.z); o.w = gelu_v<DT>(x.w);
+    }
+    return o;
+}
+
+// n8 chunks of 8 elements (16 bytes of bf16 per lane and access), grid-stride
+template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void gelu_kernel(const void* __restrict__ h, const void* __restrict__ g_a,
-                                                    void* __restrict__ out, int64_t n4) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+                                                    void* __restrict__ out, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f32x8 x = IO<DT>::load8(h, 8 * i);
+        f32x8 g = x;
+        if (BWD) g = IO<DT>::load8(g_a, 8 * i);
+        f32x8 o;
+        o.lo = gelu_apply4<DT, BWD>(x.lo, g.lo);
+        o.hi = gelu_apply4<DT, BWD>(x.hi, g.hi);
+        IO<DT>::store8(out, 8 * i, o);
+    }
+}
+// tail of fewer than 8 elements (n % 8 != 0 callers): chunks of 4
+template <int DT, bool BWD>
+__global__ __launch_bounds__(64) void gelu_tail_kernel(const void* __restrict__ h, const void* __restrict__ g_a,
+                                                        void* __restrict__ out, int64_t first4, int64_t n4) {
+    const int64_t i = first4 + threadIdx.x;
+    if (i < n4) {
         const f32x4 x = IO<DT>::load4(h, 4 * i);
-        f32x4 o;
-        if (BWD) {
-            const f32x4 g = IO<DT>::load4(g_a, 4 * i);
-            o.x = g.x * gelu_grad_f(x.x); o.y = g.y * gelu_grad_f(x.y);
-            o.z = g.z * gelu_grad_f(x.z); o.w = g.w * gelu_grad_f(x.w);
-        } else {
-            o.x = gelu_f(x.x); o.y = gelu_f(x.y); o.z = gelu_f(x.z); o.w = gelu_f(x.w);
-        }
-        IO<DT>::store4(out, 4 * i, o);
+        const f32x4 g = BWD ? IO<DT>::load4(g_a, 4 * i) : x;
+        IO<DT>::store4(out, 4 * i, gelu_apply4<DT, BWD>(x, g));
     }
 }
 
 // GELU backward that also leaves the column sums of g_h (the bias gradient of the dense layer in front of the GELU) as partial
-// rows: grid (ceil(C/1024), ceil(N/GB_ROWS)), each thread owns 4 columns and walks GB_ROWS rows with 4 loads in flight.
-constexpr int GB_ROWS = 32;
+// rows: grid (ceil(C/1024), ceil(N/GB_ROWS)) x 128 threads, each thread owns 8 columns and walks GB_ROWS rows, 4 rows in flight.
+constexpr int GB_ROWS = 8;
 template <int DT>
-__global__ __launch_bounds__(256) void gelu_bwd_bias_kernel(const void* __restrict__ h, const void* __restrict__ g_a,
+__global__ __launch_bounds__(128) void gelu_bwd_bias_kernel(const void* __restrict__ h, const void* __restrict__ g_a,
                                                              void* __restrict__ g_h, int64_t N, int64_t C, float* __restrict__ part) {
-    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t c = ((int64_t)blockIdx.x * 128 + threadIdx.x) * 8;       // 8 columns (16 bytes of bf16) per thread
     if (c >= C) return;
     const int64_t r0 = (int64_t)blockIdx.y * GB_ROWS;
     const int64_t r1 = r0 + GB_ROWS < N ? r0 + GB_ROWS : N;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
     int64_t r = r0;
     for (; r + 4 <= r1; r += 4) {
-        f32x4 x[4], g[4];
+        f32x8 x[4], g[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { x[u] = IO<DT>::load4(h, (size_t)(r + u) * C + c); g[u] = IO<DT>::load4(g_a, (size_t)(r + u) * C + c); }
+        for (int u = 0; u < 4; ++u) { x[u] = IO<DT>::load8(h, (size_t)(r + u) * C + c); g[u] = IO<DT>::load8(g_a, (size_t)(r + u) * C + c); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            f32x4 o;
-            o.x = g[u].x * gelu_grad_f(x[u].x); o.y = g[u].y * gelu_grad_f(x[u].y);
-            o.z = g[u].z * gelu_grad_f(x[u].z); o.w = g[u].w * gelu_grad_f(x[u].w);
-            IO<DT>::store4(g_h, (size_t)(r + u) * C + c, o);
-            o.x = IO<DT>::round(o.x); o.y = IO<DT>::round(o.y); o.z = IO<DT>::round(o.z); o.w = IO<DT>::round(o.w);
-            acc += o;                                  // sum what the weight-gradient GEMM will read
+            f32x8 o;
+            o.lo = gelu_apply4<DT, true>(x[u].lo, g[u].lo);
+            o.hi = gelu_apply4<DT, true>(x[u].hi, g[u].hi);
+            IO<DT>::store8(g_h, (size_t)(r + u) * C + c, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc_lo[e] += IO<DT>::round(o.lo[e]); acc_hi[e] += IO<DT>::round(o.hi[e]); }   // sum what the weight-gradient GEMM will read
         }
     }
     for (; r < r1; ++r) {
-        const f32x4 x = IO<DT>::load4(h, (size_t)r * C + c), g = IO<DT>::load4(g_a, (size_t)r * C + c);
-        f32x4 o;
-        o.x = g.x * gelu_grad_f(x.x); o.y = g.y * gelu_grad_f(x.y); o.z = g.z * gelu_grad_f(x.z); o.w = g.w * gelu_grad_f(x.w);
-        IO<DT>::store4(g_h, (size_t)r * C + c, o);
-        o.x = IO<DT>::round(o.x); o.y = IO<DT>::round(o.y); o.z = IO<DT>::round(o.z); o.w = IO<DT>::round(o.w);
-        acc += o;
+        const f32x8 x = IO<DT>::load8(h, (size_t)r * C + c), g = IO<DT>::load8(g_a, (size_t)r * C + c);
+        f32x8 o;
+        o.lo = gelu_apply4<DT, true>(x.lo, g.lo);
+        o.hi = gelu_apply4<DT, true>(x.hi, g.hi);
+        IO<DT>::store8(g_h, (size_t)r * C + c, o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc_lo[e] += IO<DT>::round(o.lo[e]); acc_hi[e] += IO<DT>::round(o.hi[e]); }
     }
-    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.y * C + c) = acc;
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.y * C + c) = acc_lo;
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.y * C + c + 4) = acc_hi;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1276,6 +1330,21 @@ using namespace kvq;
         if ((dt) == KVQ_F32) { CALL_F32; } else { CALL_BF16; } \
     } while (0)
 
+template <bool BWD>
+static int gelu_launch(const void* h, const void* g_a, void* out, int64_t n, int io_dtype, hipStream_t st) {
+    const int64_t n8 = n / 8, n4 = n / 4;
+    if (n8 > 0) {
+        unsigned blocks = (unsigned)((n8 + 255) / 256 > 16384 ? 16384 : (n8 + 255) / 256);
+        DISPATCH_DT(io_dtype, hipLaunchKernelGGL((gelu_kernel<KVQ_F32, BWD>), dim3(blocks), dim3(256), 0, st, h, g_a, out, n8),
+                    hipLaunchKernelGGL((gelu_kernel<KVQ_BF16, BWD>), dim3(blocks), dim3(256), 0, st, h, g_a, out, n8));
+    }
+    if (n4 > 2 * n8) {
+        DISPATCH_DT(io_dtype, hipLaunchKernelGGL((gelu_tail_kernel<KVQ_F32, BWD>), dim3(1), dim3(64), 0, st, h, g_a, out, 2 * n8, n4),
+                    hipLaunchKernelGGL((gelu_tail_kernel<KVQ_BF16, BWD>), dim3(1), dim3(64), 0, st, h, g_a, out, 2 * n8, n4));
+    }
+    return check_launch("gelu_kernel");
+}
+
 extern "C" {
 
 int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
@@ -1426,38 +1495,31 @@ int kvq_sum_slabs(const void* part, int S, int64_t n, int io_dtype, void* out, v
 
 int kvq_gelu_fwd(const void* h, void* a, int64_t n, int io_dtype, void* stream) {
     KVQ_REQUIRE(h && a && n > 0 && n % 4 == 0, "kvq_gelu_fwd: bad argument (n %% 4 == 0 required)");
-    const int64_t n4 = n / 4;
-    unsigned blocks = (unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DT(io_dtype, hipLaunchKernelGGL((gelu_kernel<KVQ_F32, false>), dim3(blocks), dim3(256), 0, st, h, nullptr, a, n4),
-                hipLaunchKernelGGL((gelu_kernel<KVQ_BF16, false>), dim3(blocks), dim3(256), 0, st, h, nullptr, a, n4));
-    return check_launch("gelu_kernel");
+    KVQ_REQUIRE(((uintptr_t)h | (uintptr_t)a) % 16 == 0, "kvq_gelu_fwd: 16-byte aligned buffers required");
+    return gelu_launch<false>(h, nullptr, a, n, io_dtype, (hipStream_t)stream);
 }
 
 int64_t kvq_gelu_bwd_partial_rows(int64_t N) { return (N + GB_ROWS - 1) / GB_ROWS; }
 
 int kvq_gelu_bwd_bias(const void* h, const void* g_a, void* g_h, int64_t N, int64_t C, int io_dtype, float* bias_part,
                       size_t part_bytes, void* stream) {
-    KVQ_REQUIRE(h && g_a && g_h && bias_part && N > 0 && C > 0 && C % 4 == 0, "kvq_gelu_bwd_bias: bad argument (C %% 4 == 0 required)");
+    KVQ_REQUIRE(h && g_a && g_h && bias_part && N > 0 && C > 0 && C % 8 == 0, "kvq_gelu_bwd_bias: bad argument (C %% 8 == 0 required)");
+    KVQ_REQUIRE(((uintptr_t)h | (uintptr_t)g_a | (uintptr_t)g_h | (uintptr_t)bias_part) % 16 == 0, "kvq_gelu_bwd_bias: 16-byte aligned buffers required");
     KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
     const int64_t P = (N + GB_ROWS - 1) / GB_ROWS;
     if (part_bytes < (size_t)P * C * sizeof(float)) return fail(KVQ_E_WORKSPACE, "kvq_gelu_bwd_bias: partial buffer %zu < %zu", part_bytes, (size_t)P * C * sizeof(float));
     KVQ_REQUIRE(P <= 65535, "kvq_gelu_bwd_bias: N too large");
     dim3 grid((unsigned)((C + 1023) / 1024), (unsigned)P);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(gelu_bwd_bias_kernel<KVQ_F32>, grid, dim3(256), 0, st, h, g_a, g_h, N, C, bias_part),
-                hipLaunchKernelGGL(gelu_bwd_bias_kernel<KVQ_BF16>, grid, dim3(256), 0, st, h, g_a, g_h, N, C, bias_part));
+    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(gelu_bwd_bias_kernel<KVQ_F32>, grid, dim3(128), 0, st, h, g_a, g_h, N, C, bias_part),
+                hipLaunchKernelGGL(gelu_bwd_bias_kernel<KVQ_BF16>, grid, dim3(128), 0, st, h, g_a, g_h, N, C, bias_part));
     return check_launch("gelu_bwd_bias_kernel");
 }
 
 int kvq_gelu_bwd(const void* h, const void* g_a, void* g_h, int64_t n, int io_dtype, void* stream) {
     KVQ_REQUIRE(h && g_a && g_h && n > 0 && n % 4 == 0, "kvq_gelu_bwd: bad argument (n %% 4 == 0 required)");
-    const int64_t n4 = n / 4;
-    unsigned blocks = (unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DT(io_dtype, hipLaunchKernelGGL((gelu_kernel<KVQ_F32, true>), dim3(blocks), dim3(256), 0, st, h, g_a, g_h, n4),
-                hipLaunchKernelGGL((gelu_kernel<KVQ_BF16, true>), dim3(blocks), dim3(256), 0, st, h, g_a, g_h, n4));
-    return check_launch("gelu_kernel");
+    KVQ_REQUIRE(((uintptr_t)h | (uintptr_t)g_a | (uintptr_t)g_h) % 16 == 0, "kvq_gelu_bwd: 16-byte aligned buffers required");
+    return gelu_launch<true>(h, g_a, g_h, n, io_dtype, (hipStream_t)stream);
 }
 
 int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,

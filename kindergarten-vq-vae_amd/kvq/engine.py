@@ -445,7 +445,7 @@ class TrainEngine:
                                 g_beta=fl.g(pre + "ln2.b") if tr[pre + "ln2.b"] else None,
                                 g_bias_prev=fl.g(pre + "f2.b") if tr[pre + "f2.b"] else None)
         g_a = self._linear_bwd(g_f, a, [pre + "f2.w"], [pre + "f2.b"], bias_done=True)
-        if tr[pre + "f1.b"] and h.is_contiguous() and h.shape[1] % 4 == 0:
+        if tr[pre + "f1.b"] and h.is_contiguous() and h.shape[1] % 8 == 0:
             g_h, pb = nnops.gelu_bwd_bias(h, g_a, out=g_a)           # bias gradient partials come out of the same pass
             self._defer(pb, fl.g(pre + "f1.b"), pb.shape[0], pb.shape[1], pb.shape[1])
             self._linear_bwd(g_h, x, [pre + "f1.w"], [pre + "f1.b"], gx_accum=g_x, bias_done=True)
@@ -576,7 +576,7 @@ class TrainEngine:
         g_ta, _ = self._ln_bwd(g_hN, hpre, hmean, hrstd, fl.w32("head.ln.w"), 0.0, 0, 0,
                                g_gamma=fl.g("head.ln.w") if tr["head.ln.w"] else None,
                                g_beta=fl.g("head.ln.b") if tr["head.ln.b"] else None, need_g_resid=False)
-        if tr["head.t.b"] and t.is_contiguous():
+        if tr["head.t.b"] and t.is_contiguous() and t.shape[1] % 8 == 0:
             g_t, pb = nnops.gelu_bwd_bias(t, g_ta, out=g_ta)
             self._defer(pb, fl.g("head.t.b"), pb.shape[0], pb.shape[1], pb.shape[1])
             g_y = self._linear_bwd(g_t, y, ["head.t.w"], ["head.t.b"], bias_done=True)
