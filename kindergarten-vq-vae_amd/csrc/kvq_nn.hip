@@ -344,33 +344,35 @@ struct ReduceBatch {
     int n;
 };
 constexpr int RB_SLAB_COLS = 8192;   // columns per workgroup in slab mode
-__host__ __device__ __forceinline__ bool reduce_is_slab(const kvq_reduce_item& d) {   // needs 4-element vector access
-    const uintptr_t sa = d.src_dtype == KVQ_F32 ? 15 : 7, da = d.dst_dtype == KVQ_F32 ? 15 : 7;
-    return d.count <= 32 && d.cols % 4 == 0 && d.ld % 4 == 0 && ((uintptr_t)d.src & sa) == 0 && ((uintptr_t)d.dst & da) == 0;
+__host__ __device__ __forceinline__ bool reduce_is_slab(const kvq_reduce_item& d) {   // needs 8-element (16-byte) vector access
+    return d.count <= 32 && d.cols % 8 == 0 && d.ld % 8 == 0 && ((uintptr_t)d.src & 15) == 0 && ((uintptr_t)d.dst & 15) == 0;
 }
 
 template <int DT_SRC, int DT_DST>
 __device__ __forceinline__ void reduce_slab_block(const kvq_reduce_item& d, int blk) {
-    const int64_t c0 = (int64_t)blk * RB_SLAB_COLS + 4 * threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int64_t c = c0 + 4096 * u;
-        if (c < d.cols) {
-            f32x4 a = IO<DT_SRC>::load4(d.src, c), a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
-            int64_t p = 1;
-            for (; p + 4 <= d.count; p += 4) {         // four slabs in flight; the grouping is fixed, so the sum stays deterministic
-                a += IO<DT_SRC>::load4(d.src, (size_t)p * d.ld + c);
-                a1 += IO<DT_SRC>::load4(d.src, (size_t)(p + 1) * d.ld + c);
-                a2 += IO<DT_SRC>::load4(d.src, (size_t)(p + 2) * d.ld + c);
-                a3 += IO<DT_SRC>::load4(d.src, (size_t)(p + 3) * d.ld + c);
-            }
-            for (; p < d.count; ++p) a += IO<DT_SRC>::load4(d.src, (size_t)p * d.ld + c);
-            a = (a + a1) + (a2 + a3);
-            a *= d.scale;
-            if (d.accumulate) a += IO<DT_DST>::load4(d.dst, c);
-            IO<DT_DST>::store4(d.dst, c, a);
-        }
+    // 8 columns (16 bytes of bf16) per thread; four slabs in flight; the grouping is fixed, so the sum stays deterministic
+    const int64_t c = (int64_t)blk * RB_SLAB_COLS + 8 * threadIdx.x;
+    if (c >= d.cols) return;
+    f32x8 a = IO<DT_SRC>::load8(d.src, c);
+    f32x8 a1 = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, a2 = a1, a3 = a1;
+    int64_t p = 1;
+    for (; p + 4 <= d.count; p += 4) {
+        const f32x8 t0 = IO<DT_SRC>::load8(d.src, (size_t)p * d.ld + c), t1 = IO<DT_SRC>::load8(d.src, (size_t)(p + 1) * d.ld + c);
+        const f32x8 t2 = IO<DT_SRC>::load8(d.src, (size_t)(p + 2) * d.ld + c), t3 = IO<DT_SRC>::load8(d.src, (size_t)(p + 3) * d.ld + c);
+        a.lo += t0.lo; a.hi += t0.hi; a1.lo += t1.lo; a1.hi += t1.hi;
+        a2.lo += t2.lo; a2.hi += t2.hi; a3.lo += t3.lo; a3.hi += t3.hi;
     }
+    for (; p < d.count; ++p) {
+        const f32x8 t = IO<DT_SRC>::load8(d.src, (size_t)p * d.ld + c);
+        a.lo += t.lo; a.hi += t.hi;
+    }
+    a.lo = ((a.lo + a1.lo) + (a2.lo + a3.lo)) * d.scale;
+    a.hi = ((a.hi + a1.hi) + (a2.hi + a3.hi)) * d.scale;
+    if (d.accumulate) {
+        const f32x8 o = IO<DT_DST>::load8(d.dst, c);
+        a.lo += o.lo; a.hi += o.hi;
+    }
+    IO<DT_DST>::store8(d.dst, c, a);
 }
 template <int DT_SRC, int DT_DST>
 __device__ __forceinline__ void reduce_tree_block(const kvq_reduce_item& d, int blk, float (*red)[64]) {

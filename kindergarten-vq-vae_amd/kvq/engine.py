@@ -208,7 +208,19 @@ class TrainEngine:
         for i, layer in enumerate(enc.encoder.layer):
             add_layer(f"enc.{i}.", layer, False)
         add_emb("dec.emb.", dec.bert.embeddings, pad_word_rows=self.Vp)     # tied to the LM head: padded to Vp rows
-        for i, layer in enumerate(dec.bert.encoder.layer):
+        # Every decoder layer projects the SAME encoder output (the quantised z_q) to its cross-attention keys / values
+        # (modeling_bert.py:83-85 with encoder_hidden_states): their weights sit side by side so that the 12 projections, their
+        # input gradients and their weight gradients each run as ONE GEMM over [L*2H, H] instead of 12 narrow ones.
+        dlayers = list(dec.bert.encoder.layer)
+        self._cakv_w = [n for i in range(len(dlayers)) for n in (f"dec.{i}.ca.k.w", f"dec.{i}.ca.v.w")]
+        self._cakv_b = [n for i in range(len(dlayers)) for n in (f"dec.{i}.ca.k.b", f"dec.{i}.ca.v.b")]
+        for i, layer in enumerate(dlayers):
+            sx = layer.crossattention.self
+            add(f"dec.{i}.ca.k.w", sx.key.weight); add(f"dec.{i}.ca.v.w", sx.value.weight)
+        for i, layer in enumerate(dlayers):
+            sx = layer.crossattention.self
+            add(f"dec.{i}.ca.k.b", sx.key.bias); add(f"dec.{i}.ca.v.b", sx.value.bias)
+        for i, layer in enumerate(dlayers):
             add_layer(f"dec.{i}.", layer, True)
         head = dec.cls.predictions
         add("head.t.w", head.transform.dense.weight); add("head.t.b", head.transform.dense.bias)
@@ -221,6 +233,8 @@ class TrainEngine:
         self.n_enc_layers = len(enc.encoder.layer)
         self.n_dec_layers = len(dec.bert.encoder.layer)
         self.nh = self.ecfg.num_attention_heads
+        flags = {self.flat.trainable[n] for n in self._cakv_w + self._cakv_b}
+        self._cakv_batched = len(flags) == 1 and self.n_dec_layers > 0       # mixed frozen / trained layers: per-layer GEMMs
         if self.has_vq:
             vq = model.vector_quantizer
             self.E = vq.embedding.weight                      # f32 parameter, own tiny Adam state (f32 gradient)
@@ -368,8 +382,9 @@ class TrainEngine:
             gt.zero_()
             gt[0] = g_pt.float().sum(0).to(gt.dtype)
 
-    def _attn_block_fwd(self, pre, x, kv_src, mask, causal, cfg, training, B, Sq, Sk):
-        """self-attention (kv_src is None) or cross-attention on kv_src; returns LN(dropout(dense(ctx)) + x)."""
+    def _attn_block_fwd(self, pre, x, kv_src, mask, causal, cfg, training, B, Sq, Sk, kv_pre=None):
+        """self-attention (kv_src is None) or cross-attention on kv_src (kv_pre: its already projected [N, 2H] keys | values,
+        a column slice of the all-layer projection); returns LN(dropout(dense(ctx)) + x)."""
         fl, H, nh = self.flat, self.H, self.nh
         p_attn = cfg.attention_probs_dropout_prob if training else 0.0
         p_hid = cfg.hidden_dropout_prob if training else 0.0
@@ -380,7 +395,8 @@ class TrainEngine:
             kvbuf = None
         else:
             qkv = self._linear(x, pre + "q.w", pre + "q.b")
-            kvbuf = self._linear(kv_src, None, None, fused=([pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"]))
+            kvbuf = kv_pre if kv_pre is not None else \
+                self._linear(kv_src, None, None, fused=([pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"]))
             q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
         ctx, _ = nnops.attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a)
         ao = self._linear(ctx, pre + "o.w", pre + "o.b")
@@ -388,8 +404,9 @@ class TrainEngine:
                                               p_hid, self._step_seed, site_o)
         return out, (x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk)
 
-    def _attn_block_bwd(self, pre, g_out, saved, g_kv_src=None):
-        """returns g_x; for cross-attention accumulates the gradient of kv_src into g_kv_src."""
+    def _attn_block_bwd(self, pre, g_out, saved, g_kv_src=None, g_kv_out=None, pb_kv_out=None):
+        """returns g_x; for cross-attention accumulates the gradient of kv_src into g_kv_src -- or, in the batched layout, only
+        leaves g_kv (and its bias partial rows) in the given column slices for the all-layer GEMMs after the decoder loop."""
         fl, H, nh = self.flat, self.H, self.nh
         x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk = saved
         tr = fl.trainable
@@ -413,16 +430,20 @@ class TrainEngine:
             self._linear_bwd(g_qkv, x, [pre + "q.w", pre + "k.w", pre + "v.w"], [pre + "q.b", pre + "k.b", pre + "v.b"], gx_accum=g_x,
                              bias_done=want_b)
         else:
-            g_kv = torch.empty_like(kvbuf)
+            batched = g_kv_out is not None
+            g_kv = g_kv_out if batched else torch.empty_like(kvbuf)
             pbq = torch.empty((B, H), dtype=torch.float32, device=self.dev) if want_b else None
-            pbkv = torch.empty((B, 2 * H), dtype=torch.float32, device=self.dev) if want_b else None
+            want_bkv = tr[pre + "k.b"]
+            pbkv = (pb_kv_out if batched else torch.empty((B, 2 * H), dtype=torch.float32, device=self.dev)) if want_bkv else None
             nnops.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], mask, g_ctx, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a,
-                           g_qkv, g_kv[:, :H], g_kv[:, H:], *((pbq, pbkv[:, :H], pbkv[:, H:]) if want_b else ()))
+                           g_qkv, g_kv[:, :H], g_kv[:, H:], pbq, pbkv[:, :H] if want_bkv else None, pbkv[:, H:] if want_bkv else None)
             if want_b:
                 self._defer(pbq, fl.g(pre + "q.b"), B, H, H)
-                self._defer(pbkv, fl.fused([pre + "k.b", pre + "v.b"], fl.grad), B, 2 * H, 2 * H)
             self._linear_bwd(g_qkv, x, [pre + "q.w"], [pre + "q.b"], gx_accum=g_x, bias_done=want_b)
-            self._linear_bwd(g_kv, kv_src, [pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"], gx_accum=g_kv_src, bias_done=want_b)
+            if not batched:
+                if want_bkv:
+                    self._defer(pbkv, fl.fused([pre + "k.b", pre + "v.b"], fl.grad), B, 2 * H, 2 * H)
+                self._linear_bwd(g_kv, kv_src, [pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"], gx_accum=g_kv_src, bias_done=want_bkv)
         return g_x
 
     def _ffn_fwd(self, pre, x, cfg, training):
@@ -534,9 +555,13 @@ class TrainEngine:
 
         y, demb_saved = self._emb_fwd("dec.emb.", dcfg, input_ids, training, word_rows=None)
         dec_saved = []
+        kv_all = None
+        if self._cakv_batched:             # keys | values of every decoder layer's cross-attention in one [N, L*2H] GEMM
+            kv_all = torch.addmm(fl.fused(self._cakv_b, fl.shadow), enc_out, fl.fused(self._cakv_w, fl.shadow).t())
         for i in range(self.n_dec_layers):
             y, sa = self._attn_block_fwd(f"dec.{i}.sa.", y, None, mask, True, dcfg, training, B, S, S)
-            y, ca = self._attn_block_fwd(f"dec.{i}.ca.", y, enc_out, None, False, dcfg, training, B, S, S)
+            y, ca = self._attn_block_fwd(f"dec.{i}.ca.", y, enc_out, None, False, dcfg, training, B, S, S,
+                                         kv_pre=kv_all[:, 2 * H * i: 2 * H * (i + 1)] if kv_all is not None else None)
             y, ff = self._ffn_fwd(f"dec.{i}.", y, dcfg, training)
             dec_saved.append((sa, ca, ff))
         t = self._linear(y, "head.t.w", "head.t.b")
@@ -567,10 +592,7 @@ class TrainEngine:
         if tr["head.bias"]:
             self._defer_colsum(g_logits, fl.g("head.bias", rows=self.Vp))
         if tr["dec.emb.word"]:
-            # [Vp,H] = g_logits^T hN is faster computed as its transpose (H rows x Vp columns) and flipped once
-            gWt = torch.mm(hN.t(), g_logits)
-            fl.g("dec.emb.word", rows=self.Vp).copy_(gWt.t())
-            del gWt
+            torch.mm(g_logits.t(), hN, out=fl.g("dec.emb.word", rows=self.Vp))      # [Vp,H] = g_logits^T hN
         g_hN = torch.mm(g_logits, Wv)
         del logits, g_logits
         g_ta, _ = self._ln_bwd(g_hN, hpre, hmean, hrstd, fl.w32("head.ln.w"), 0.0, 0, 0,
@@ -584,14 +606,32 @@ class TrainEngine:
             g_t = nnops.gelu_bwd(t, g_ta, out=g_ta)
             g_y = self._linear_bwd(g_t, y, ["head.t.w"], ["head.t.b"])
         self._grads_done_down_to("head.t.w")
-        g_enc = torch.zeros_like(enc_out)
+        g_kv_all = pb_kv_all = None
+        if self._cakv_batched:
+            g_kv_all = torch.empty_like(kv_all)
+            if tr[self._cakv_b[0]]:
+                pb_kv_all = torch.empty((B, kv_all.shape[1]), dtype=torch.float32, device=self.dev)
+            g_enc = None
+        else:
+            g_enc = torch.zeros_like(enc_out)
         for i in reversed(range(self.n_dec_layers)):
             sa, ca, ff = dec_saved[i]
             g_y = self._ffn_bwd(f"dec.{i}.", g_y, ff)
-            g_y = self._attn_block_bwd(f"dec.{i}.ca.", g_y, ca, g_kv_src=g_enc)
+            sl = slice(2 * H * i, 2 * H * (i + 1))
+            g_y = self._attn_block_bwd(f"dec.{i}.ca.", g_y, ca, g_kv_src=g_enc,
+                                       g_kv_out=g_kv_all[:, sl] if g_kv_all is not None else None,
+                                       pb_kv_out=pb_kv_all[:, sl] if pb_kv_all is not None else None)
             g_y = self._attn_block_bwd(f"dec.{i}.sa.", g_y, sa)
             self._grads_done_down_to(f"dec.{i}.sa.q.w")
             dec_saved[i] = None
+        if self._cakv_batched:             # all layers' key/value projections at once: weight, bias and input gradients
+            if tr[self._cakv_w[0]]:
+                torch.mm(g_kv_all.t(), enc_out, out=fl.fused(self._cakv_w, fl.grad))
+            if pb_kv_all is not None:
+                self._defer(pb_kv_all, fl.fused(self._cakv_b, fl.grad), B, pb_kv_all.shape[1], pb_kv_all.shape[1])
+            g_enc = torch.mm(g_kv_all, fl.fused(self._cakv_w, fl.shadow))
+            del g_kv_all, kv_all
+            self._grads_done_down_to(self._cakv_w[0])
         self._emb_bwd("dec.emb.", g_y, demb_saved, tied_accumulate=True)
         self._grads_done_down_to("dec.emb.word")
         if self.has_vq:
