@@ -256,6 +256,28 @@ int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                   void* stream);
 
+
+/* ---- device-resident step state (hipGraph-friendly training step) ------------------------------------------------------
+ * step_state: 24 bytes of device memory, zero-initialised = "no optimiser step applied yet":
+ *     struct { uint64_t step; float lr, bc1, bc2s, pad; }
+ * kvq_step_state_advance   one-thread kernel run at the start of an optimiser step: step += 1, lr = lr0 * gamma^(number of
+ *                          milestones <= step-1)  (torch MultiStepLR ticked once per finished step, Trainer.py:114-115),
+ *                          bc1 = 1 - beta1^step, bc2s = sqrt(1 - beta2^step).  At most 8 milestones (host array).
+ * kvq_adam_step_dev        kvq_adam_step reading lr / bias corrections from the step state instead of taking them by value.
+ * kvq_set_seed_offset      library-wide: every dropout-bearing kernel launched afterwards (kvq_dropout,
+ *                          kvq_dropout_residual_ln_*, kvq_attn_*) uses seed + step_state->step, read on the device at run
+ *                          time; NULL switches it off.  A step captured once in a hipGraph then replays with fresh masks,
+ *                          the right learning rate and bias corrections, with nothing patched from the host.
+ * kvq_dropout              out = x * keep/(1-p) for the Philox mask of (seed, site); element i draws from call i/4 like the
+ *                          other kernels.  Forward and (applied to the gradient) backward of a plain dropout.  n %% 4 == 0. */
+int kvq_step_state_advance(void* step_state, float lr0, float gamma, const int64_t* milestones, int n_milestones, float beta1,
+                           float beta2, void* stream);
+int kvq_adam_step_dev(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
+                      const void* step_state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                      void* stream);
+int kvq_set_seed_offset(const void* step_state);
+int kvq_dropout(const void* x, int64_t n, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

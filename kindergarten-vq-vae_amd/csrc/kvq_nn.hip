@@ -61,9 +61,11 @@ template <int DT, int PER>
 __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ y, const void* __restrict__ resid,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int64_t N, int H, float eps, float p_drop, unsigned thresh,
-                                                        unsigned long long seed, unsigned site, void* __restrict__ out,
+                                                        unsigned long long seed, const unsigned long long* __restrict__ seed_off,
+                                                        unsigned site, void* __restrict__ out,
                                                         void* __restrict__ pre, float* __restrict__ mean_out,
                                                         float* __restrict__ rstd_out) {
+    if (seed_off) seed += *seed_off;          // device-resident step counter: a captured graph replays with fresh masks
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
@@ -126,10 +128,12 @@ template <int DT, int PER>
 __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ g_out, const void* __restrict__ pre,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, int64_t N, int H, float p_drop,
-                                                        unsigned thresh, unsigned long long seed, unsigned site,
+                                                        unsigned thresh, unsigned long long seed,
+                                                        const unsigned long long* __restrict__ seed_off, unsigned site,
                                                         void* __restrict__ g_y, void* __restrict__ g_resid,
                                                         float* __restrict__ part_dgamma, int want_dbias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][3][H]
+    if (seed_off) seed += *seed_off;
     constexpr int RW = LNB_ROWS / 4;                              // rows per wave
     constexpr int RF = PER <= 4 ? RW : 1;                         // ... of which RF are in flight at once (register budget)
     typedef typename std::conditional<(PER > 8), unsigned long long, unsigned>::type KeepBits;   // 4 bits per chunk
@@ -542,7 +546,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                     float* __restrict__ v, float* __restrict__ vmax,
                                                     unsigned short* __restrict__ shadow, int64_t n4, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    float grad_scale) {
+                                                    float grad_scale, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }     // device-resident step state (kvq_step_state_advance)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         f32x4 pv = *reinterpret_cast<f32x4*>(p + 4 * i);
         f32x4 gv = IO<DT_G>::load4(g, 4 * i) * grad_scale;
@@ -568,6 +573,50 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
         *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
         if (shadow) IO<KVQ_BF16>::store4(shadow, 4 * i, pv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device-resident step state: what changes from one training step to the next (step count -> dropout seed offset, learning
+// rate after the MultiStepLR milestones, Adam bias corrections) lives in 24 bytes of HBM and is advanced by a one-thread kernel,
+// so that a whole step captured in a hipGraph replays without any host-side argument patching.
+// ---------------------------------------------------------------------------------------------------------------
+struct StepState {
+    unsigned long long step;   // optimiser steps completed; dropout kernels add it to their seed
+    float lr, bc1, bc2s, pad;  // for the step being applied: lr after milestones, 1 - beta1^t, sqrt(1 - beta2^t)
+};
+struct Milestones {
+    long long at[8];
+    int n;
+};
+__global__ void step_state_advance_kernel(StepState* st, float lr0, float gamma, Milestones ms, float beta1, float beta2) {
+    const unsigned long long t = st->step + 1;             // the step now being applied (1-based)
+    int k = 0;
+    for (int i = 0; i < ms.n; ++i) k += ((long long)(t - 1) >= ms.at[i]) ? 1 : 0;   // MultiStepLR ticked once per finished step
+    double lr = lr0;
+    for (int i = 0; i < k; ++i) lr *= (double)gamma;
+    st->lr = (float)lr;
+    st->bc1 = (float)(1.0 - pow((double)beta1, (double)t));
+    st->bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    st->step = t;
+}
+
+// out = x * keep / (1-p) with the Philox mask of (seed, site): the dropout behind the embedding LayerNorm (modeling_bert.py:58,
+// BertEmbeddings) and, applied to the incoming gradient, its backward
+template <int DT>
+__global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n4, float p_drop,
+                                                       unsigned thresh, unsigned long long seed,
+                                                       const unsigned long long* __restrict__ seed_off, unsigned site) {
+    if (seed_off) seed += *seed_off;
+    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 a = IO<DT>::load4(x, 4 * i);
+        if (p_drop > 0.f) {
+            const U4 b = drop_bits(seed, site, (unsigned long long)i);
+            a.x *= keep_scale(b.x, thresh, inv_keep); a.y *= keep_scale(b.y, thresh, inv_keep);
+            a.z *= keep_scale(b.z, thresh, inv_keep); a.w *= keep_scale(b.w, thresh, inv_keep);
+        }
+        IO<DT>::store4(out, 4 * i, a);
     }
 }
 
@@ -598,6 +647,7 @@ struct AttnParams {
     float scale, p_drop;
     unsigned thresh;
     unsigned long long seed;
+    const unsigned long long* seed_off;   // optional device-resident addend of the seed (see kvq_set_seed_offset)
     unsigned site;
 };
 
@@ -657,10 +707,11 @@ __device__ __forceinline__ int attn_key(int h, int jj) { return LAY ? 8 * (jj >>
 template <int LAY = 0>
 __device__ __forceinline__ void attn_keep16(const AttnParams& p, int bh, int i, int h, float (&keep)[16]) {
     const float inv_keep = 1.0f / (1.0f - p.p_drop);
+    const unsigned long long seed = p.seed + (p.seed_off ? *p.seed_off : 0ull);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const unsigned long long e4 = (((unsigned long long)bh * AT_S + i) * AT_S + attn_key<LAY>(h, 4 * c)) >> 2;
-        const U4 r = drop_bits(p.seed, p.site, e4);
+        const U4 r = drop_bits(seed, p.site, e4);
         keep[4 * c] = keep_scale(r.x, p.thresh, inv_keep); keep[4 * c + 1] = keep_scale(r.y, p.thresh, inv_keep);
         keep[4 * c + 2] = keep_scale(r.z, p.thresh, inv_keep); keep[4 * c + 3] = keep_scale(r.w, p.thresh, inv_keep);
     }
@@ -1327,6 +1378,8 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
 
 using namespace kvq;
 
+static const unsigned long long* g_seed_off = nullptr;   // kvq_set_seed_offset
+
 #define DISPATCH_DT(dt, CALL_F32, CALL_BF16) \
     do {                                     \
         if ((dt) == KVQ_F32) { CALL_F32; } else { CALL_BF16; } \
@@ -1361,7 +1414,7 @@ int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* g
     const unsigned th = drop_threshold(p_drop);
 #define LAUNCH_LN_FWD(DTV, PERV)                                                                                          \
     hipLaunchKernelGGL((drln_fwd_kernel<DTV, PERV>), grid, dim3(256), 0, st, y, resid, gamma, beta, N, H, eps, p_drop, th, \
-                       (unsigned long long)seed, site, out, pre, mean, rstd)
+                       (unsigned long long)seed, g_seed_off, site, out, pre, mean, rstd)
     if (H <= 768) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 3), LAUNCH_LN_FWD(KVQ_BF16, 3)); }
     else if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 4), LAUNCH_LN_FWD(KVQ_BF16, 4)); }
     else { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 16), LAUNCH_LN_FWD(KVQ_BF16, 16)); }
@@ -1401,7 +1454,7 @@ int kvq_dropout_residual_ln_bwd_partial(const void* g_out, const void* pre, cons
     const unsigned th = drop_threshold(p_drop);
 #define LAUNCH_LN_BWD(DTV, PERV)                                                                                             \
     hipLaunchKernelGGL((drln_bwd_kernel<DTV, PERV>), dim3((unsigned)blocks), dim3(256), lds, st, g_out, pre, mean, rstd, gamma, \
-                       N, H, p_drop, th, (unsigned long long)seed, site, g_y, g_resid, pdg, want_dbias ? 1 : 0)
+                       N, H, p_drop, th, (unsigned long long)seed, g_seed_off, site, g_y, g_resid, pdg, want_dbias ? 1 : 0)
     if (H <= 768) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 3), LAUNCH_LN_BWD(KVQ_BF16, 3)); }
     else if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 4), LAUNCH_LN_BWD(KVQ_BF16, 4)); }
     else { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 16), LAUNCH_LN_BWD(KVQ_BF16, 16)); }
@@ -1524,21 +1577,65 @@ int kvq_gelu_bwd(const void* h, const void* g_a, void* g_h, int64_t n, int io_dt
     return gelu_launch<true>(h, g_a, g_h, n, io_dtype, (hipStream_t)stream);
 }
 
-int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
-                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
-                  void* stream) {
-    KVQ_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "kvq_adam_step: bad argument (n %% 4 == 0, step >= 1)");
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+static int adam_launch(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2s, float grad_scale,
+                       const float* hyper, void* stream) {
+    KVQ_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0, "kvq_adam_step: bad argument (n %% 4 == 0)");
     const int64_t n4 = n / 4;
     unsigned blocks = (unsigned)((n4 + 255) / 256 > 32768 ? 32768 : (n4 + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DT(grad_dtype,
                 hipLaunchKernelGGL(adam_kernel<KVQ_F32>, dim3(blocks), dim3(256), 0, st, p, g, m, v, vmax, (unsigned short*)shadow_bf16, n4,
-                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale),
+                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper),
                 hipLaunchKernelGGL(adam_kernel<KVQ_BF16>, dim3(blocks), dim3(256), 0, st, p, g, m, v, vmax, (unsigned short*)shadow_bf16, n4,
-                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale));
+                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper));
     return check_launch("adam_kernel");
+}
+
+int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                  void* stream) {
+    KVQ_REQUIRE(step >= 1, "kvq_adam_step: step >= 1");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    return adam_launch(p, g, m, v, vmax, shadow_bf16, n, grad_dtype, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, nullptr, stream);
+}
+
+int kvq_adam_step_dev(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
+                      const void* step_state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                      void* stream) {
+    KVQ_REQUIRE(step_state, "kvq_adam_step_dev: null step state");
+    return adam_launch(p, g, m, v, vmax, shadow_bf16, n, grad_dtype, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale,
+                       reinterpret_cast<const float*>(reinterpret_cast<const char*>(step_state) + 8), stream);
+}
+
+int kvq_step_state_advance(void* step_state, float lr0, float gamma, const int64_t* milestones, int n_milestones, float beta1,
+                           float beta2, void* stream) {
+    KVQ_REQUIRE(step_state && n_milestones >= 0 && n_milestones <= 8 && (n_milestones == 0 || milestones),
+                "kvq_step_state_advance: bad argument (at most 8 milestones)");
+    Milestones ms = {};
+    ms.n = n_milestones;
+    for (int i = 0; i < n_milestones; ++i) ms.at[i] = milestones[i];
+    hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (StepState*)step_state, lr0, gamma, ms, beta1, beta2);
+    return check_launch("step_state_advance_kernel");
+}
+
+int kvq_set_seed_offset(const void* step_state) {
+    g_seed_off = reinterpret_cast<const unsigned long long*>(step_state);
+    return KVQ_OK;
+}
+
+int kvq_dropout(const void* x, int64_t n, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* stream) {
+    KVQ_REQUIRE(x && out && n > 0 && n % 4 == 0, "kvq_dropout: bad argument (n %% 4 == 0 required)");
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
+    KVQ_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop out of range");
+    const int64_t n4 = n / 4;
+    unsigned blocks = (unsigned)((n4 + 255) / 256 > 16384 ? 16384 : (n4 + 255) / 256);
+    const unsigned th = drop_threshold(p_drop);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(io_dtype, hipLaunchKernelGGL(dropout_kernel<KVQ_F32>, dim3(blocks), dim3(256), 0, st, x, out, n4, p_drop, th, (unsigned long long)seed, g_seed_off, site),
+                hipLaunchKernelGGL(dropout_kernel<KVQ_BF16>, dim3(blocks), dim3(256), 0, st, x, out, n4, p_drop, th, (unsigned long long)seed, g_seed_off, site));
+    return check_launch("dropout_kernel");
 }
 
 static int g_attn_variant = 2;   // bf16 io: 2 = MFMA kernels, 1 = packed-dot kernels (v_dot2c_f32_bf16), 0 = convert-and-fma kernels
@@ -1566,7 +1663,7 @@ int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mas
     AttnParams p = {};
     p.q = q; p.k = k; p.v = v; p.out = out; p.lse = lse; p.mask = mask;
     p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.causal = causal;
-    p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.site = site;
+    p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.seed_off = g_seed_off; p.site = site;
     hipStream_t st = (hipStream_t)stream;
     const bool al = (ldq % 8 == 0) && (ldk % 8 == 0) && (ldv % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0);
     if (io_dtype == KVQ_F32) hipLaunchKernelGGL(attn_fwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
@@ -1597,7 +1694,7 @@ int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mas
                 "kvq_attn_bwd: bias partial row strides must cover nh*64 columns");
     p.pb_q = bias_part_q; p.pb_k = bias_part_k; p.pb_v = bias_part_v; p.ldp_q = ldp_q; p.ldp_kv = ldp_kv;
     p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.causal = causal;
-    p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.site = site;
+    p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.seed_off = g_seed_off; p.site = site;
     hipStream_t st = (hipStream_t)stream;
     const bool al = (ldq % 8 == 0) && (ldk % 8 == 0) && (ldv % 8 == 0) && (ldo % 8 == 0) &&
                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)g_out | (uintptr_t)g_q | (uintptr_t)g_k | (uintptr_t)g_v) % 16 == 0);

@@ -70,6 +70,10 @@ SIGNATURES = {
     "kvq_gemm_nt_bf16_dgelu": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_attn_set_variant": (_int, [_int]),
     "kvq_adam_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "kvq_step_state_advance": (_int, [_vp, _f32, _f32, C.POINTER(_i64), _int, _f32, _f32, _vp]),
+    "kvq_adam_step_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "kvq_set_seed_offset": (_int, [_vp]),
+    "kvq_dropout": (_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp]),
 }
 
 _lib = None

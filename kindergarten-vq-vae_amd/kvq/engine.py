@@ -23,6 +23,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -138,6 +140,60 @@ class FlatParams:
             self.shadow.copy_(self.master)
 
 
+class _StepGraphs:
+    """One training step of a fixed batch shape as two hipGraphs around the eager quantiser launch.
+
+    graph 1: embeddings + encoder forward            (reads the static ids / mask, leaves z)
+    eager  : kvq_vq_forward(z) -> static z_q, idx, [loss, perplexity]     (timed by bench.py's HIP events)
+    graph 2: decoder forward, loss, whole backward, step-state advance, Adam
+    Nothing in the graphs depends on host values that change between steps: see the device step state in include/kvq.h."""
+
+    def __init__(self, eng, ids, mask):
+        self.eng = eng
+        dev = eng.dev
+        self.ids, self.mask = ids.clone(), mask.contiguous().clone()
+        N, H = ids.numel(), eng.H
+        self.z_q = torch.empty((N, H), dtype=eng.dtype, device=dev)
+        self.idx = torch.empty(N, dtype=torch.int64, device=dev)
+        self.vq_out = torch.empty(2, dtype=torch.float32, device=dev)
+        self.z = None
+        self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        step0 = eng._step_host
+        with torch.cuda.stream(side):
+            eng._cap = self
+            try:
+                self.g1.capture_begin()
+                self.out = eng.forward_backward(self.ids, self.mask, training=eng.model.training, compute_grads=True)
+                eng.optimizer_step()
+                self.g2.capture_end()
+            finally:
+                eng._cap = None
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        eng._step_host = step0              # capturing ran no kernel: the device state did not move either
+
+    # called by the engine at the quantiser, in the middle of the captured forward
+    def end_first(self, z):
+        self.z = z
+        self.g1.capture_end()
+
+    def begin_second(self):
+        self.g2.capture_begin(pool=self.g1.pool())
+
+    def run(self, ids, mask):
+        eng = self.eng
+        self.ids.copy_(ids)
+        self.mask.copy_(mask)
+        self.g1.replay()
+        eng._vq_forward(self.z, self.z_q, self.idx, self.vq_out)
+        self.g2.replay()
+        eng._step_host += 1
+        return {k: (v.clone() if v is not None else None) for k, v in self.out.items()}   # the graph's buffers are overwritten next step
+
+
 class TrainEngine:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False,
                  milestones=None, gamma=0.1, loss_recon_scale=1.0, loss_vq_scale=1.0, seed=1234,
@@ -161,7 +217,16 @@ class TrainEngine:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.milestones, self.gamma = sorted(milestones or []), gamma
         self.w_recon, self.w_vq = float(loss_recon_scale), float(loss_vq_scale)
-        self.seed, self.step_count = int(seed), 0
+        self.seed = int(seed)
+        if len(self.milestones) > 8:
+            raise KvqError("TrainEngine: at most 8 LR milestones (kvq_step_state_advance)")
+        # what changes from step to step lives on the device (include/kvq.h "step state"): dropout kernels add the step count
+        # to their seed, Adam reads lr and the bias corrections -- so a captured hipGraph of the whole step can be replayed
+        self._state = nnops.new_step_state(dev)
+        self._step_host = 0
+        self._step_seed = (self.seed * 1000003) & 0x7FFFFFFFFFFFFFF      # + step count on the device
+        self._graphs, self._eager_seen, self._cap = {}, {}, None
+        self.use_graph = os.environ.get("KVQ_GRAPH", "1") != "0"
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
 
@@ -250,11 +315,20 @@ class TrainEngine:
         self._works = []
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         _load_gemm_tuning()
-        self._gen = torch.Generator(device=dev)
 
     # ------------------------------------------------------------------------------------------------------------
     # small helpers
     # ------------------------------------------------------------------------------------------------------------
+    @property
+    def step_count(self):
+        """Optimiser steps applied so far (host mirror of the device step state)."""
+        return self._step_host
+
+    @step_count.setter
+    def step_count(self, n):
+        self._step_host = int(n)
+        self._state[0] = int(n)          # lr / bias corrections are recomputed by the next kvq_step_state_advance
+
     def _lr_now(self):
         """MultiStepLR ticked once per optimiser step (Trainer.py:114-115): the s-th step (1-based) sees s-1 ticks."""
         ticks = self.step_count - 1
@@ -349,9 +423,8 @@ class TrainEngine:
         keep = None
         p = cfg.hidden_dropout_prob if training else 0.0
         if p > 0:
-            self._gen.manual_seed(self._step_seed * 64 + self._site())        # reproducible per (step, site), like the Philox sites
-            keep = (torch.rand(out.shape, dtype=torch.float32, device=self.dev, generator=self._gen) >= p).to(out.dtype) * (1.0 / (1.0 - p))
-            out = out * keep
+            keep = (p, self._site())                              # the mask is regenerated in backward from (seed, site)
+            out = nnops.dropout(out, p, self._step_seed, keep[1], out=out)
         return out, (ids, pre, mean, rstd, keep)
 
     def _emb_bwd(self, prefix, g, saved, tied_accumulate=False):
@@ -359,7 +432,7 @@ class TrainEngine:
         ids, pre, mean, rstd, keep = saved
         B, S = ids.shape
         if keep is not None:
-            g = g * keep
+            g = nnops.dropout(g, keep[0], self._step_seed, keep[1])
         tr = fl.trainable
         g_y, g_pt = nnops.ln_bwd(g, pre, mean, rstd, fl.w32(prefix + "ln.w"),
                                  g_gamma=fl.g(prefix + "ln.w") if tr[prefix + "ln.w"] else None,
@@ -528,7 +601,17 @@ class TrainEngine:
             raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
         self._site_ctr = 0
         self._red_items, self._red_keep = [], []
-        self._step_seed = (self.seed * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
+        nnops.set_seed_offset(self._state)        # dropout seeds of this engine's launches = _step_seed + device step count
+        try:
+            return self._forward_backward(input_ids, attention_mask, training, compute_grads)
+        finally:
+            nnops.set_seed_offset(None)
+
+    def _forward_backward(self, input_ids, attention_mask, training, compute_grads):
+        m = self.model
+        fl, H = self.flat, self.H
+        B, S = input_ids.shape
+        N = B * S
         mask = attention_mask.contiguous()
         ecfg, dcfg = self.ecfg, self.dcfg
 
@@ -541,13 +624,17 @@ class TrainEngine:
             enc_saved.append((sa, ff))
         z = x
         if self.has_vq:
-            ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, self.E.shape[0], H, 1))
-            z_q = torch.empty_like(z)
-            idx = torch.empty(N, dtype=torch.int64, device=self.dev)
-            vq_out = torch.empty(2, dtype=torch.float32, device=self.dev)
-            check(lib().kvq_vq_forward(z.data_ptr(), self.E.data_ptr(), N, self.E.shape[0], H, 1, self.io, self.beta_vq,
-                                       z_q.data_ptr(), idx.data_ptr(), vq_out[0:].data_ptr(), vq_out[1:].data_ptr(), None,
-                                       ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward")
+            cap = self._cap
+            if cap is not None:                     # graph capture: the quantiser stays OUTSIDE the two graphs (it is the
+                cap.end_first(z)                    # kernel bench.py times with HIP events on every launch)
+                z_q, idx, vq_out = cap.z_q, cap.idx, cap.vq_out
+            else:
+                z_q = torch.empty_like(z)
+                idx = torch.empty(N, dtype=torch.int64, device=self.dev)
+                vq_out = torch.empty(2, dtype=torch.float32, device=self.dev)
+            self._vq_forward(z, z_q, idx, vq_out)
+            if cap is not None:
+                cap.begin_second()
             loss_vq, perplexity = vq_out[0], vq_out[1]
             enc_out = z_q
         else:
@@ -658,19 +745,27 @@ class TrainEngine:
         self._flush_reductions()
         return out
 
+    def _vq_forward(self, z, z_q, idx, vq_out):
+        N, H = z.shape
+        ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, self.E.shape[0], H, 1))
+        check(lib().kvq_vq_forward(z.data_ptr(), self.E.data_ptr(), N, self.E.shape[0], H, 1, self.io, self.beta_vq,
+                                   z_q.data_ptr(), idx.data_ptr(), vq_out[0:].data_ptr(), vq_out[1:].data_ptr(), None,
+                                   ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward")
+
     def optimizer_step(self):
         self._grads_finish()
-        self.step_count += 1
-        lr = self._lr_now()
+        self._step_host += 1
         fl = self.flat
         b1, b2 = self.betas
+        # step += 1, lr after the milestones, bias corrections: computed on the device, read there by the Adam kernels
+        nnops.step_state_advance(self._state, self.lr, self.gamma, self.milestones, b1, b2)
         for (a, b) in fl.ranges:
-            nnops.adam_step(fl.master[a:b], fl.grad[a:b], fl.m[a:b], fl.v[a:b], self.step_count, lr, b1, b2, self.eps, self.wd,
-                            vmax=fl.vmax[a:b] if fl.vmax is not None else None,
-                            shadow=fl.shadow[a:b] if fl.shadow is not fl.master else None)
+            nnops.adam_step_dev(fl.master[a:b], fl.grad[a:b], fl.m[a:b], fl.v[a:b], self._state, b1, b2, self.eps, self.wd,
+                                vmax=fl.vmax[a:b] if fl.vmax is not None else None,
+                                shadow=fl.shadow[a:b] if fl.shadow is not fl.master else None)
         if self.has_vq and self.E.requires_grad:
-            nnops.adam_step(self.E.data.view(-1), self.gE.view(-1), self.mE.view(-1), self.vE.view(-1), self.step_count, lr,
-                            b1, b2, self.eps, self.wd, vmax=self.vmaxE.view(-1) if self.vmaxE is not None else None)
+            nnops.adam_step_dev(self.E.data.view(-1), self.gE.view(-1), self.mE.view(-1), self.vE.view(-1), self._state,
+                                b1, b2, self.eps, self.wd, vmax=self.vmaxE.view(-1) if self.vmaxE is not None else None)
 
     def sync_from_model(self):
         """Call after the model's parameters were written from outside (load_state_dict, manual init): refreshes the bf16
@@ -683,10 +778,26 @@ class TrainEngine:
         cfg = model.encoder.config
         return cfg.hidden_size // cfg.num_attention_heads == 64 and seq_len <= 32 and cfg.hidden_size % 32 == 0
 
-    def train_step(self, input_ids, attention_mask):
+    def _train_step_eager(self, input_ids, attention_mask):
         out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True)
         self.optimizer_step()
         return out
+
+    def train_step(self, input_ids, attention_mask):
+        """One optimiser step.  Single-GPU runs replay the step from two hipGraphs (everything before / after the quantiser,
+        which stays an eager launch) once a batch shape has been seen twice; the host then issues three launches per step
+        instead of ~800.  Multi-GPU runs (RCCL exchange overlapped with backward) and KVQ_GRAPH=0 stay eager."""
+        if not (self.use_graph and self.world == 1 and self.has_vq):
+            return self._train_step_eager(input_ids, attention_mask)
+        key = (tuple(input_ids.shape), bool(self.model.training))
+        g = self._graphs.get(key)
+        if g is None:
+            seen = self._eager_seen.get(key, 0)
+            if seen < 2 or len(self._graphs) >= 4:      # warm the workspaces / GEMM plans eagerly first; few shapes only
+                self._eager_seen[key] = seen + 1
+                return self._train_step_eager(input_ids, attention_mask)
+            g = self._graphs[key] = _StepGraphs(self, input_ids, attention_mask)
+        return g.run(input_ids, attention_mask)
 
     def eval_step(self, input_ids, attention_mask):
         return self.forward_backward(input_ids, attention_mask, training=False, compute_grads=False)

