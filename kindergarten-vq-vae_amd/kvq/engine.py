@@ -141,12 +141,15 @@ class FlatParams:
 
 
 class _StepGraphs:
-    """One training step of a fixed batch shape as two hipGraphs around the eager quantiser launch.
+    """One training step of a fixed batch shape as a chain of hipGraphs with eager launches in between.
 
-    graph 1: embeddings + encoder forward            (reads the static ids / mask, leaves z)
-    eager  : kvq_vq_forward(z) -> static z_q, idx, [loss, perplexity]     (timed by bench.py's HIP events)
-    graph 2: decoder forward, loss, whole backward, step-state advance, Adam
-    Nothing in the graphs depends on host values that change between steps: see the device step state in include/kvq.h."""
+    The step is captured once; wherever the engine has something that must stay an ordinary launch it calls interlude(fn):
+    the running capture ends, fn is kept (and run once), the next capture begins in the same memory pool.  Interludes are
+      * the quantiser forward (kvq_vq_forward: the kernel bench.py times with HIP events on every launch), and
+      * on multi-GPU runs every gradient all-reduce (RCCL, issued on the side stream while the next graph runs) and the
+        final wait for them before the Adam graph.
+    Replay = graph, interlude, graph, ...: ~3 host launches per step on one GPU instead of ~800.  Nothing inside the graphs
+    depends on host values that change between steps: see the device step state in include/kvq.h."""
 
     def __init__(self, eng, ids, mask):
         self.eng = eng
@@ -156,8 +159,7 @@ class _StepGraphs:
         self.z_q = torch.empty((N, H), dtype=eng.dtype, device=dev)
         self.idx = torch.empty(N, dtype=torch.int64, device=dev)
         self.vq_out = torch.empty(2, dtype=torch.float32, device=dev)
-        self.z = None
-        self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.graphs, self.inter = [torch.cuda.CUDAGraph()], []
         side = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -165,32 +167,35 @@ class _StepGraphs:
         with torch.cuda.stream(side):
             eng._cap = self
             try:
-                self.g1.capture_begin()
+                # thread-local capture mode: the process group's helper threads (gloo copies, the RCCL watchdog's event queries)
+                # keep issuing HIP calls on their own streams while this thread captures
+                self.graphs[0].capture_begin(capture_error_mode="thread_local")
                 self.out = eng.forward_backward(self.ids, self.mask, training=eng.model.training, compute_grads=True)
                 eng.optimizer_step()
-                self.g2.capture_end()
+                self.graphs[-1].capture_end()
             finally:
                 eng._cap = None
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        eng._step_host = step0              # capturing ran no kernel: the device state did not move either
+        eng._step_host = step0              # capturing ran no captured kernel: the device step state did not move either
 
-    # called by the engine at the quantiser, in the middle of the captured forward
-    def end_first(self, z):
-        self.z = z
-        self.g1.capture_end()
-
-    def begin_second(self):
-        self.g2.capture_begin(pool=self.g1.pool())
+    def interlude(self, fn):
+        """Called by the engine in the middle of the captured step: fn stays an eager launch between two graphs."""
+        self.graphs[-1].capture_end()
+        fn()
+        self.inter.append(fn)
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self.graphs[0].pool(), capture_error_mode="thread_local")
+        self.graphs.append(g)
 
     def run(self, ids, mask):
-        eng = self.eng
         self.ids.copy_(ids)
         self.mask.copy_(mask)
-        self.g1.replay()
-        eng._vq_forward(self.z, self.z_q, self.idx, self.vq_out)
-        self.g2.replay()
-        eng._step_host += 1
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.inter):
+                self.inter[i]()
+        self.eng._step_host += 1
         return {k: (v.clone() if v is not None else None) for k, v in self.out.items()}   # the graph's buffers are overwritten next step
 
 
@@ -569,8 +574,25 @@ class TrainEngine:
             else:
                 self._works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
 
+    def _eager(self, fn):
+        """Run fn now; while a step is being captured it also becomes an eager launch between two graphs of the replay."""
+        if self._cap is not None:
+            self._cap.interlude(fn)
+        else:
+            fn()
+
     def _reduce(self, a, b):
-        self._all_reduce_avg(self.flat.grad[a:b])
+        t = self.flat.grad[a:b]
+        self._eager(lambda: self._all_reduce_avg(t))
+
+    def _wait_reductions(self):
+        with torch.cuda.stream(self.comm_stream):     # work.wait() orders the CURRENT stream behind the collective's result:
+            for w, t in self._works:                  # the side stream must be the one that waits before it divides
+                w.wait()
+                if t is not None:
+                    t.div_(self.world)
+        self._works = []
+        torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
 
     def _grads_finish(self):
         if self.world == 1:
@@ -578,14 +600,8 @@ class TrainEngine:
         if self._pending_hi > 0:
             self._reduce(0, self._pending_hi)
         if self.has_vq:
-            self._all_reduce_avg(self.gE)
-        for w, t in self._works:
-            w.wait()
-            if t is not None:
-                with torch.cuda.stream(self.comm_stream):
-                    t.div_(self.world)
-        self._works = []
-        torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
+            self._eager(lambda: self._all_reduce_avg(self.gE))
+        self._eager(self._wait_reductions)
         self._pending_hi = self.flat.n
 
     # ------------------------------------------------------------------------------------------------------------
@@ -625,16 +641,13 @@ class TrainEngine:
         z = x
         if self.has_vq:
             cap = self._cap
-            if cap is not None:                     # graph capture: the quantiser stays OUTSIDE the two graphs (it is the
-                cap.end_first(z)                    # kernel bench.py times with HIP events on every launch)
+            if cap is not None:                     # graph capture: the quantiser stays an eager launch between two graphs
                 z_q, idx, vq_out = cap.z_q, cap.idx, cap.vq_out
             else:
                 z_q = torch.empty_like(z)
                 idx = torch.empty(N, dtype=torch.int64, device=self.dev)
                 vq_out = torch.empty(2, dtype=torch.float32, device=self.dev)
-            self._vq_forward(z, z_q, idx, vq_out)
-            if cap is not None:
-                cap.begin_second()
+            self._eager(lambda: self._vq_forward(z, z_q, idx, vq_out))
             loss_vq, perplexity = vq_out[0], vq_out[1]
             enc_out = z_q
         else:
@@ -784,10 +797,10 @@ class TrainEngine:
         return out
 
     def train_step(self, input_ids, attention_mask):
-        """One optimiser step.  Single-GPU runs replay the step from two hipGraphs (everything before / after the quantiser,
-        which stays an eager launch) once a batch shape has been seen twice; the host then issues three launches per step
-        instead of ~800.  Multi-GPU runs (RCCL exchange overlapped with backward) and KVQ_GRAPH=0 stay eager."""
-        if not (self.use_graph and self.world == 1 and self.has_vq):
+        """One optimiser step.  Once a batch shape has been seen twice the step is replayed from a chain of hipGraphs
+        (_StepGraphs: the quantiser and, on multi-GPU runs, the RCCL all-reduces stay eager launches between the graphs); the
+        host then issues a handful of launches per step instead of ~800.  KVQ_GRAPH=0 keeps every launch eager."""
+        if not self.use_graph:
             return self._train_step_eager(input_ids, attention_mask)
         key = (tuple(input_ids.shape), bool(self.model.training))
         g = self._graphs.get(key)
