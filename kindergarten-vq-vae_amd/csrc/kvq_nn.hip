@@ -297,33 +297,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restr
     }
 }
 
-// grid ceil(C/64), 1024 threads = 16 partial-phases x 64 columns; fixed summation order
-template <int DT_OUT>
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int64_t P, int64_t C, int64_t ldp,
-                                                             void* __restrict__ out, float scale, int accumulate) {
-    __shared__ float red[16][64];
-    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const int64_t c = (int64_t)blockIdx.x * 64 + cl;
-    float a0 = 0.f, a1 = 0.f;
-    if (c < C) {
-        int64_t p = ph;
-        for (; p + 16 < P; p += 32) {
-            a0 += part[(size_t)p * ldp + c];
-            a1 += part[(size_t)(p + 16) * ldp + c];
-        }
-        for (; p < P; p += 16) a0 += part[(size_t)p * ldp + c];
-    }
-    red[ph][cl] = a0 + a1;
-    __syncthreads();
-    if (ph == 0 && c < C) {
-        float a = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a += red[q][cl];
-        a *= scale;
-        if (accumulate) a += IO<DT_OUT>::load1(out, c);
-        IO<DT_OUT>::store1(out, c, a);
-    }
-}
 
 // out[i] = sum_s part[s*n + i]  (f32 accumulate over S split-K slabs of a weight-gradient GEMM), 8 elements per thread
 template <int DT>
@@ -380,23 +353,48 @@ __device__ __forceinline__ void reduce_slab_block(const kvq_reduce_item& d, int 
 }
 template <int DT_SRC, int DT_DST>
 __device__ __forceinline__ void reduce_tree_block(const kvq_reduce_item& d, int blk, float (*red)[64]) {
-    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const int64_t c = (int64_t)blk * 64 + cl;
-    float a0 = 0.f, a1 = 0.f;
-    if (c < d.cols) {
-        int64_t p = ph;
-        for (; p + 16 < d.count; p += 32) {
-            a0 += IO<DT_SRC>::load1(d.src, (size_t)p * d.ld + c);
-            a1 += IO<DT_SRC>::load1(d.src, (size_t)(p + 16) * d.ld + c);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool vec = d.cols % 4 == 0 && d.ld % 4 == 0 && ((uintptr_t)d.src % (4 * IO<DT_SRC>::bytes)) == 0;   // block-uniform
+    if (vec) {
+        // 64 columns x 64 row phases: a lane owns 4 columns (one 16-byte access), a wave covers 4 rows x 64 columns
+        const int cg = lane & 15, ph = threadIdx.x >> 4;
+        const int64_t c = (int64_t)blk * 64 + 4 * cg;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        if (c < d.cols) {
+            int64_t p = ph;
+            for (; p + 64 < d.count; p += 128) {
+                a0 += IO<DT_SRC>::load4(d.src, (size_t)p * d.ld + c);
+                a1 += IO<DT_SRC>::load4(d.src, (size_t)(p + 64) * d.ld + c);
+            }
+            for (; p < d.count; p += 64) a0 += IO<DT_SRC>::load4(d.src, (size_t)p * d.ld + c);
         }
-        for (; p < d.count; p += 16) a0 += IO<DT_SRC>::load1(d.src, (size_t)p * d.ld + c);
+        a0 += a1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                       // the wave's 4 phases of one column group sit 16 lanes apart
+            a0[e] += __shfl_xor(a0[e], 16, WAVE);
+            a0[e] += __shfl_xor(a0[e], 32, WAVE);
+        }
+        if (lane < 16) *reinterpret_cast<f32x4*>(&red[w][4 * cg]) = a0;
+    } else {
+        const int cl = lane, ph = w;
+        const int64_t c = (int64_t)blk * 64 + cl;
+        float a0 = 0.f, a1 = 0.f;
+        if (c < d.cols) {
+            int64_t p = ph;
+            for (; p + 16 < d.count; p += 32) {
+                a0 += IO<DT_SRC>::load1(d.src, (size_t)p * d.ld + c);
+                a1 += IO<DT_SRC>::load1(d.src, (size_t)(p + 16) * d.ld + c);
+            }
+            for (; p < d.count; p += 16) a0 += IO<DT_SRC>::load1(d.src, (size_t)p * d.ld + c);
+        }
+        red[ph][cl] = a0 + a1;
     }
-    red[ph][cl] = a0 + a1;
     __syncthreads();
-    if (ph == 0 && c < d.cols) {
+    const int64_t c = (int64_t)blk * 64 + lane;
+    if (w == 0 && c < d.cols) {
         float a = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a += red[q][cl];
+        for (int q = 0; q < 16; ++q) a += red[q][lane];
         a *= d.scale;
         if (d.accumulate) a += IO<DT_DST>::load1(d.dst, c);
         IO<DT_DST>::store1(d.dst, c, a);
@@ -1429,10 +1427,11 @@ size_t kvq_ln_bwd_workspace_bytes(int64_t N, int H) {
 
 static int colsum_f32_partials(const float* part, int64_t P, int64_t C, int64_t ldp, void* out, int out_dtype, float scale,
                                int accumulate, hipStream_t st) {
-    dim3 grid((unsigned)((C + 63) / 64));
-    DISPATCH_DT(out_dtype, hipLaunchKernelGGL(colsum_final_kernel<KVQ_F32>, grid, dim3(1024), 0, st, part, P, C, ldp, out, scale, accumulate),
-                hipLaunchKernelGGL(colsum_final_kernel<KVQ_BF16>, grid, dim3(1024), 0, st, part, P, C, ldp, out, scale, accumulate));
-    return check_launch("colsum_final_kernel");
+    // the final sum of partial rows is the one-item case of the batched reduction: same kernel, same summation order
+    kvq_reduce_item it = {};
+    it.src = part; it.dst = out; it.count = P; it.cols = C; it.ld = ldp; it.scale = scale;
+    it.src_dtype = KVQ_F32; it.dst_dtype = out_dtype; it.accumulate = accumulate;
+    return kvq_reduce_batch(&it, 1, st);
 }
 
 int64_t kvq_ln_bwd_partial_rows(int64_t N) { return (N + LNB_ROWS - 1) / LNB_ROWS; }

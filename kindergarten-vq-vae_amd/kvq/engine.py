@@ -344,9 +344,15 @@ class TrainEngine:
         self._site_ctr += 1
         return self._site_ctr
 
+    # (N, K) of the forward projections where csrc/kvq_gemm.hip beats the tuned library (tools/gemm_own_probe.py on MI355X:
+    # 8192x768x768 17.2 us vs 20.7 us); every other shape stays with hipBLASLt
+    _OWN_GEMM = {(768, 768)}
+
     def _linear(self, x, wname, bname, fused=None):
         W = self.flat.fused(fused[0], self.flat.shadow) if fused else self.flat.w(wname)
         b = self.flat.fused(fused[1], self.flat.shadow) if fused else self.flat.w(bname)
+        if self.dtype == torch.bfloat16 and tuple(W.shape) in self._OWN_GEMM and x.shape[0] >= 2048 and x.is_contiguous():
+            return nnops.gemm_nt(x, W, b)
         return torch.addmm(b, x, W.t())
 
     # split-K factors for the weight-gradient GEMMs gW[M,N] = gy[Ntok,M]^T x[Ntok,N]: the contraction (Ntok = 8192) is long
