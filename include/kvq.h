@@ -278,6 +278,17 @@ int kvq_adam_step_dev(float* p, const void* g, float* m, float* v, float* vmax, 
 int kvq_set_seed_offset(const void* step_state);
 int kvq_dropout(const void* x, int64_t n, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* stream);
 
+
+/* Word-embedding gradient (autograd of the row gather of BertEmbeddings, modeling_bert.py:53-58):
+ *     gW[id][:] (= | +=) sum over the tokens n with ids[n] == id of g[n][:],   tokens added in increasing n  (deterministic)
+ * The caller passes the tokens sorted by id: sorted_ids[s] ascending and perm[s] = the token at sorted position s (a STABLE
+ * sort, e.g. torch.sort(ids, stable=True)); the same pair serves every embedding table looked up with these ids.
+ * g [N, H] (g_dtype), gW [V, H] (w_dtype); with accumulate == 0 only the rows of ids that occur are written (zero gW first),
+ * ids outside [0, V) are ignored.  H %% 4 == 0, H <= 1024.  No float atomics. */
+size_t kvq_embed_grad_workspace_bytes(int64_t N, int H);
+int kvq_embed_grad(const void* g, const int64_t* perm, const int64_t* sorted_ids, int64_t N, int H, int64_t V, int g_dtype,
+                   void* gW, int w_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -619,6 +619,134 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Word-embedding gradient (autograd of the gather in BertEmbeddings, modeling_bert.py:53-58): gW[id] (= | +=) sum over the
+// tokens n with ids[n] == id of g[n], tokens visited in increasing n.  Input is the token order sorted by id (stable), so
+// every id is one run of consecutive positions.  Deterministic: no float atomics (torch's index_add_ is an atomic scatter
+// whose hot row -- the pad token, ~60 % of all positions -- serialises: 157 us per call at N = 8192).
+//   pass 1  one wave per block of EG_R sorted positions walks its runs; a run that lies inside the block is final and is
+//           written straight to gW; a run cut by a block boundary leaves an f32 partial row (head / tail slot of the block)
+//   pass 2  one wave per block that holds the FIRST piece of a cut run adds the following blocks' head pieces in order
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int EG_R = 32;   // sorted positions per wave
+
+template <int DT_G, int DT_W, int PER>
+__device__ __forceinline__ void eg_emit(const f32x4 (&acc)[PER], void* gW, long long id, int H, int lane, int accumulate) {
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int c = lane + WAVE * t;
+        if (4 * c < H) {
+            f32x4 a = acc[t];
+            const size_t off = (size_t)id * H + 4 * c;
+            if (accumulate) a += IO<DT_W>::load4(gW, off);
+            IO<DT_W>::store4(gW, off, a);
+        }
+    }
+}
+
+// edge layout: edge[(2 b + slot) * H ..], slot 0 = head piece (continues a run of the previous block), 1 = tail piece that
+// STARTS a cut run; meta[b] bit 0: has tail piece, bit 1: the head piece covers the whole block and the run goes on
+template <int DT_G, int DT_W, int PER>
+__global__ __launch_bounds__(64) void embed_grad_runs_kernel(const void* __restrict__ g, const int64_t* __restrict__ perm,
+                                                              const int64_t* __restrict__ sid, int64_t N, int H, int64_t V,
+                                                              void* __restrict__ gW, int accumulate, float* __restrict__ edge,
+                                                              int* __restrict__ meta) {
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x, s0 = b * EG_R;
+    const int64_t s1 = s0 + EG_R < N ? s0 + EG_R : N;
+    const int n = (int)(s1 - s0);
+    // lane l keeps position s0 + l's id and token (lanes >= n mirror the last one)
+    const int64_t my = s0 + (lane < n ? lane : n - 1);
+    const long long my_id = sid[my], my_tok = perm[my];
+    const bool head_cont = s0 > 0 && sid[s0 - 1] == sid[s0];
+    const bool tail_cont = s1 < N && sid[s1] == sid[s1 - 1];
+    f32x4 acc[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) acc[t] = 0.f;
+    int m = 0;
+    int run_start = 0;
+    long long cur = __shfl(my_id, 0, WAVE);
+    for (int i0 = 0; i0 < n; i0 += 4) {                      // four rows in flight
+        f32x4 v[4][PER];
+        long long ids4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u < n ? i0 + u : n - 1;
+            ids4[u] = __shfl(my_id, i, WAVE);
+            const long long tok = __shfl(my_tok, i, WAVE);
+#pragma unroll
+            for (int t = 0; t < PER; ++t) {
+                const int c = lane + WAVE * t;
+                v[u][t] = IO<DT_G>::load4(g, (size_t)tok * H + 4 * (4 * c < H ? c : 0));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i >= n) break;                               // wave-uniform
+            if (ids4[u] != cur) {                            // wave-uniform: the run [run_start, i) of id `cur` is complete
+                if (run_start == 0 && head_cont) {
+#pragma unroll
+                    for (int t = 0; t < PER; ++t) { const int c = lane + WAVE * t; if (4 * c < H) *reinterpret_cast<f32x4*>(edge + (size_t)(2 * b) * H + 4 * c) = acc[t]; }
+                } else if (cur >= 0 && cur < V) {
+                    eg_emit<DT_G, DT_W, PER>(acc, gW, cur, H, lane, accumulate);
+                }
+#pragma unroll
+                for (int t = 0; t < PER; ++t) acc[t] = 0.f;
+                cur = ids4[u];
+                run_start = i;
+            }
+#pragma unroll
+            for (int t = 0; t < PER; ++t) acc[t] += v[u][t];
+        }
+    }
+    // last run [run_start, n)
+    const bool first_piece_of_cut = tail_cont && !(run_start == 0 && head_cont);
+    if (run_start == 0 && head_cont) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) { const int c = lane + WAVE * t; if (4 * c < H) *reinterpret_cast<f32x4*>(edge + (size_t)(2 * b) * H + 4 * c) = acc[t]; }
+        if (tail_cont) m |= 2;                               // the whole block is the middle of a run
+    } else if (first_piece_of_cut) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) { const int c = lane + WAVE * t; if (4 * c < H) *reinterpret_cast<f32x4*>(edge + (size_t)(2 * b + 1) * H + 4 * c) = acc[t]; }
+        m |= 1;
+    } else if (cur >= 0 && cur < V) {
+        eg_emit<DT_G, DT_W, PER>(acc, gW, cur, H, lane, accumulate);
+    }
+    if (lane == 0) meta[b] = m;
+}
+
+template <int DT_W, int PER>
+__global__ __launch_bounds__(64) void embed_grad_edges_kernel(const int64_t* __restrict__ sid, int64_t N, int H, int64_t V,
+                                                               void* __restrict__ gW, int accumulate, const float* __restrict__ edge,
+                                                               const int* __restrict__ meta, int64_t nblocks) {
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    if (!(meta[b] & 1)) return;                              // no cut run starts in this block
+    const int64_t s1 = (b + 1) * EG_R < N ? (b + 1) * EG_R : N;
+    const long long id = sid[s1 - 1];
+    f32x4 acc[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) { const int c = lane + WAVE * t; acc[t] = 4 * c < H ? *reinterpret_cast<const f32x4*>(edge + (size_t)(2 * b + 1) * H + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int64_t bb = b + 1; bb < nblocks; ++bb) {           // head pieces of the following blocks, in order
+#pragma unroll
+        for (int t = 0; t < PER; ++t) { const int c = lane + WAVE * t; if (4 * c < H) acc[t] += *reinterpret_cast<const f32x4*>(edge + (size_t)(2 * bb) * H + 4 * c); }
+        if (!(meta[bb] & 2)) break;                          // that head piece ended inside its block
+    }
+    if (id >= 0 && id < V) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int c = lane + WAVE * t;
+            if (4 * c < H) {
+                f32x4 a = acc[t];
+                const size_t off = (size_t)id * H + 4 * c;
+                if (accumulate) a += IO<DT_W>::load4(gW, off);
+                IO<DT_W>::store4(gW, off, a);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Attention for short sentences: S_q, S_k <= 32, head dim 64.  One wave per (sentence, head).
 //   lane = (query i = lane & 31, half h = lane >> 5).  QK^T: the lane scores its query against keys 16h..16h+15
 //   (K rows are LDS broadcasts); softmax row = 16 in-lane values + one exchange with lane^32; PV: the lane produces
@@ -1617,6 +1745,44 @@ int kvq_step_state_advance(void* step_state, float lr0, float gamma, const int64
     for (int i = 0; i < n_milestones; ++i) ms.at[i] = milestones[i];
     hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (StepState*)step_state, lr0, gamma, ms, beta1, beta2);
     return check_launch("step_state_advance_kernel");
+}
+
+size_t kvq_embed_grad_workspace_bytes(int64_t N, int H) {
+    const int64_t nb = (N + EG_R - 1) / EG_R;
+    return (size_t)nb * 2 * H * sizeof(float) + (size_t)nb * sizeof(int);
+}
+
+int kvq_embed_grad(const void* g, const int64_t* perm, const int64_t* sorted_ids, int64_t N, int H, int64_t V, int g_dtype,
+                   void* gW, int w_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    KVQ_REQUIRE(g && perm && sorted_ids && gW && N > 0 && V > 0, "kvq_embed_grad: bad argument");
+    KVQ_REQUIRE(H > 0 && H % 4 == 0 && H <= 1024, "kvq_embed_grad: H=%d unsupported (multiple of 4, <= 1024)", H);
+    KVQ_REQUIRE((g_dtype == KVQ_F32 || g_dtype == KVQ_BF16) && (w_dtype == KVQ_F32 || w_dtype == KVQ_BF16), "unsupported dtype");
+    const size_t need = kvq_embed_grad_workspace_bytes(N, H);
+    if (!ws || ws_bytes < need) return fail(KVQ_E_WORKSPACE, "kvq_embed_grad: workspace %zu < %zu", ws_bytes, need);
+    const int64_t nb = (N + EG_R - 1) / EG_R;
+    float* edge = (float*)ws;
+    int* meta = (int*)((char*)ws + (size_t)nb * 2 * H * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    const int per = (H / 4 + WAVE - 1) / WAVE;               // 1..4
+#define EG_LAUNCH(DG, DW, P)                                                                                                   \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((embed_grad_runs_kernel<DG, DW, P>), dim3((unsigned)nb), dim3(64), 0, st, g, perm, sorted_ids, N, H, V, \
+                           gW, accumulate, edge, meta);                                                                        \
+        hipLaunchKernelGGL((embed_grad_edges_kernel<DW, P>), dim3((unsigned)nb), dim3(64), 0, st, sorted_ids, N, H, V, gW,      \
+                           accumulate, (const float*)edge, (const int*)meta, nb);                                             \
+    } while (0)
+#define EG_PER(DG, DW)                                                                       \
+    do {                                                                                     \
+        if (per == 1) EG_LAUNCH(DG, DW, 1); else if (per == 2) EG_LAUNCH(DG, DW, 2);         \
+        else if (per == 3) EG_LAUNCH(DG, DW, 3); else EG_LAUNCH(DG, DW, 4);                  \
+    } while (0)
+    if (g_dtype == KVQ_F32 && w_dtype == KVQ_F32) EG_PER(KVQ_F32, KVQ_F32);
+    else if (g_dtype == KVQ_BF16 && w_dtype == KVQ_BF16) EG_PER(KVQ_BF16, KVQ_BF16);
+    else if (g_dtype == KVQ_BF16 && w_dtype == KVQ_F32) EG_PER(KVQ_BF16, KVQ_F32);
+    else EG_PER(KVQ_F32, KVQ_BF16);
+#undef EG_PER
+#undef EG_LAUNCH
+    return check_launch("embed_grad_kernel");
 }
 
 int kvq_set_seed_offset(const void* step_state) {

@@ -73,6 +73,8 @@ SIGNATURES = {
     "kvq_step_state_advance": (_int, [_vp, _f32, _f32, C.POINTER(_i64), _int, _f32, _f32, _vp]),
     "kvq_adam_step_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "kvq_set_seed_offset": (_int, [_vp]),
+    "kvq_embed_grad_workspace_bytes": (_sz, [_i64, _int]),
+    "kvq_embed_grad": (_int, [_vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _int, _int, _vp, _sz, _vp]),
     "kvq_dropout": (_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp]),
 }
 

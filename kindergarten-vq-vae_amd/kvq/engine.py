@@ -450,13 +450,21 @@ class TrainEngine:
                                  g_beta=fl.g(prefix + "ln.b") if tr[prefix + "ln.b"] else None)
         if tr[prefix + "word"]:
             o, n, shape = fl.seg[prefix + "word"]
-            acc = torch.zeros(shape, dtype=torch.float32, device=self.dev)
-            acc.index_add_(0, ids.reshape(-1), g_y.float())
             gw = fl.grad[o:o + n].view(shape)
-            if tied_accumulate:
-                gw.add_(acc.to(gw.dtype))          # LM-head weight gradient is already in there
+            if g_y.shape[1] % 4 == 0 and g_y.shape[1] <= 1024:
+                # deterministic segmented sum over the tokens sorted by id (one stable sort per step serves both tables)
+                if self._sorted_ids is None:
+                    self._sorted_ids = torch.sort(ids.reshape(-1), stable=True)
+                if not tied_accumulate:
+                    gw.zero_()
+                nnops.embed_grad(g_y, self._sorted_ids[1], self._sorted_ids[0], gw, accumulate=tied_accumulate)
             else:
-                gw.copy_(acc)
+                acc = torch.zeros(shape, dtype=torch.float32, device=self.dev)
+                acc.index_add_(0, ids.reshape(-1), g_y.float())
+                if tied_accumulate:
+                    gw.add_(acc.to(gw.dtype))          # LM-head weight gradient is already in there
+                else:
+                    gw.copy_(acc)
         if tr[prefix + "pos"]:
             gp = fl.g(prefix + "pos")
             gp.zero_()
@@ -623,6 +631,7 @@ class TrainEngine:
             raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
         self._site_ctr = 0
         self._red_items, self._red_keep = [], []
+        self._sorted_ids = None
         nnops.set_seed_offset(self._state)        # dropout seeds of this engine's launches = _step_seed + device step count
         try:
             return self._forward_backward(input_ids, attention_mask, training, compute_grads)

@@ -207,6 +207,18 @@ def dropout(x, p_drop, seed, site, out=None):
     return o
 
 
+def embed_grad(g, perm, sorted_ids, gW, accumulate=False):
+    """gW[id] (= | +=) sum of g[n] over the tokens with that id, in token order (deterministic, no atomics).
+    perm / sorted_ids: stable sort of the flattened ids (sorted_ids, perm = torch.sort(ids.reshape(-1), stable=True))."""
+    require_gpu(g, gW)
+    N, H = g.shape
+    l = lib()
+    ws = _workspace(g.device, l.kvq_embed_grad_workspace_bytes(N, H), tag="embed_grad")
+    check(l.kvq_embed_grad(g.data_ptr(), perm.data_ptr(), sorted_ids.data_ptr(), N, H, gW.shape[0], io_dtype_of(g), gW.data_ptr(),
+                           io_dtype_of(gW), int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_embed_grad")
+    return gW
+
+
 def gemm_nt(a, b, bias=None, out=None, accumulate=False):
     """out[M,N] (= | +=) a[M,K] @ b[N,K].T (+ bias), bf16, hand-written MFMA kernel (csrc/kvq_gemm.hip)."""
     require_gpu(a, b)

@@ -341,3 +341,38 @@ def test_step_state_and_adam_dev(ops):
         ops.adam_step_dev(p, g, m, v, st)
         ops.adam_step(p2, g, m2, v2, step, want_lr)
         torch.testing.assert_close(p, p2, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("H,gdt,wdt", [(768, torch.bfloat16, torch.bfloat16), (128, torch.float32, torch.float32), (1024, torch.bfloat16, torch.float32), (100, torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("pattern", ["padded", "one-id", "unique", "blocks"])
+def test_embed_grad_matches_index_add(ops, H, gdt, wdt, pattern):
+    """Sorted-run embedding gradient vs index_add_ in f64: runs cut by block boundaries (hot pad row), single runs, all-unique
+    ids, runs that end exactly on a block boundary; '=' and '+=' forms; out-of-range ids ignored."""
+    torch.manual_seed(H)
+    V, N = 1000, 2048 + 17
+    if pattern == "padded":
+        ids = torch.randint(1, V, (N,), device="cuda")
+        ids[torch.rand(N, device="cuda") < 0.6] = 0
+    elif pattern == "one-id":
+        ids = torch.full((N,), 7, device="cuda")
+    elif pattern == "unique":
+        ids = torch.randperm(N, device="cuda") % V
+        ids = torch.arange(N, device="cuda") % V if V >= N else torch.randperm(V, device="cuda").repeat((N + V - 1) // V)[:N]
+    else:
+        ids = (torch.arange(N, device="cuda") // 32) % V            # every run is exactly one block of 32
+        ids[5] = V + 3                                               # ignored
+    g = torch.randn(N, H, device="cuda").to(gdt)
+    sid, perm = torch.sort(ids.reshape(-1), stable=True)
+    ok = ids < V
+    ref = torch.zeros(V, H, device="cuda", dtype=torch.float64).index_add_(0, ids[ok], g[ok].double())
+    tol = dict(rtol=1e-2, atol=3e-2) if wdt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-4)
+    gw = torch.zeros(V, H, device="cuda", dtype=wdt)
+    ops.embed_grad(g, perm, sid, gw)
+    torch.testing.assert_close(gw.double(), ref, **tol)
+    base = torch.randn(V, H, device="cuda").to(wdt)
+    gw2 = base.clone()
+    ops.embed_grad(g, perm, sid, gw2, accumulate=True)
+    torch.testing.assert_close(gw2.double(), base.double() + ref, **(dict(rtol=2e-2, atol=6e-2) if wdt == torch.bfloat16 else tol))
+    gw3 = torch.zeros(V, H, device="cuda", dtype=wdt)
+    ops.embed_grad(g, perm, sid, gw3)
+    assert torch.equal(gw3, gw)                                       # deterministic
