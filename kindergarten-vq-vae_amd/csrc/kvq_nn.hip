@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ x
 //           written straight to gW; a run cut by a block boundary leaves an f32 partial row (head / tail slot of the block)
 //   pass 2  one wave per block that holds the FIRST piece of a cut run adds the following blocks' head pieces in order
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int EG_R = 32;   // sorted positions per wave
+constexpr int EG_R = 8;    // sorted positions per wave: one batch of row loads, 1024 waves at N = 8192
 
 template <int DT_G, int DT_W, int PER>
 __device__ __forceinline__ void eg_emit(const f32x4 (&acc)[PER], void* gW, long long id, int H, int lane, int accumulate) {
@@ -665,11 +665,12 @@ __global__ __launch_bounds__(64) void embed_grad_runs_kernel(const void* __restr
     int m = 0;
     int run_start = 0;
     long long cur = __shfl(my_id, 0, WAVE);
-    for (int i0 = 0; i0 < n; i0 += 4) {                      // four rows in flight
-        f32x4 v[4][PER];
-        long long ids4[4];
+    constexpr int EG_FLY = EG_R;                             // every row of the block in flight at once
+    for (int i0 = 0; i0 < n; i0 += EG_FLY) {
+        f32x4 v[EG_FLY][PER];
+        long long ids4[EG_FLY];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < EG_FLY; ++u) {
             const int i = i0 + u < n ? i0 + u : n - 1;
             ids4[u] = __shfl(my_id, i, WAVE);
             const long long tok = __shfl(my_tok, i, WAVE);
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(64) void embed_grad_runs_kernel(const void* __restr
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < EG_FLY; ++u) {
             const int i = i0 + u;
             if (i >= n) break;                               // wave-uniform
             if (ids4[u] != cur) {                            // wave-uniform: the run [run_start, i) of id `cur` is complete
@@ -715,33 +716,70 @@ __global__ __launch_bounds__(64) void embed_grad_runs_kernel(const void* __restr
     if (lane == 0) meta[b] = m;
 }
 
+// pass 2: 16 waves per cut run.  The run's pieces are the tail piece of block b and the head pieces of blocks b+1 .. b+np;
+// wave w adds pieces w, w+16, ... in order, the 16 partial rows are then added in wave order: a fixed tree, deterministic.
 template <int DT_W, int PER>
-__global__ __launch_bounds__(64) void embed_grad_edges_kernel(const int64_t* __restrict__ sid, int64_t N, int H, int64_t V,
-                                                               void* __restrict__ gW, int accumulate, const float* __restrict__ edge,
-                                                               const int* __restrict__ meta, int64_t nblocks) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(1024) void embed_grad_edges_kernel(const int64_t* __restrict__ sid, int64_t N, int H, int64_t V,
+                                                                void* __restrict__ gW, int accumulate, const float* __restrict__ edge,
+                                                                const int* __restrict__ meta, int64_t nblocks) {
+    __shared__ __attribute__((aligned(16))) float red[16][PER * 256];
+    __shared__ int np_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t b = blockIdx.x;
-    if (!(meta[b] & 1)) return;                              // no cut run starts in this block
-    const int64_t s1 = (b + 1) * EG_R < N ? (b + 1) * EG_R : N;
-    const long long id = sid[s1 - 1];
+    if (!(meta[b] & 1)) return;                              // no cut run starts in this block (workgroup-uniform)
+    if (w == 0) {                                            // how many following blocks carry a head piece of this run
+        int np = 0;
+        for (int64_t k = b + 1;; k += 64) {
+            const int64_t bb = k + lane;
+            const bool last = bb >= nblocks || !(meta[bb] & 2);      // this head piece ends the run (or there is none)
+            const unsigned long long m = __ballot(last);
+            if (m) { np += __ffsll((long long)m); break; }
+            np += 64;
+        }
+        if (lane == 0) np_s = np;
+    }
+    __syncthreads();
+    const int np = np_s;
     f32x4 acc[PER];
 #pragma unroll
-    for (int t = 0; t < PER; ++t) { const int c = lane + WAVE * t; acc[t] = 4 * c < H ? *reinterpret_cast<const f32x4*>(edge + (size_t)(2 * b + 1) * H + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int64_t bb = b + 1; bb < nblocks; ++bb) {           // head pieces of the following blocks, in order
+    for (int t = 0; t < PER; ++t) acc[t] = 0.f;
+    if (w == 0) {
 #pragma unroll
-        for (int t = 0; t < PER; ++t) { const int c = lane + WAVE * t; if (4 * c < H) acc[t] += *reinterpret_cast<const f32x4*>(edge + (size_t)(2 * bb) * H + 4 * c); }
-        if (!(meta[bb] & 2)) break;                          // that head piece ended inside its block
+        for (int t = 0; t < PER; ++t) { const int c = lane + WAVE * t; if (4 * c < H) acc[t] = *reinterpret_cast<const f32x4*>(edge + (size_t)(2 * b + 1) * H + 4 * c); }
     }
-    if (id >= 0 && id < V) {
+    for (int j0 = w; j0 < np; j0 += 128) {                   // pieces j0, j0+16, ..., j0+112: eight loads in flight
+        f32x4 v[8][PER];
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int c = lane + WAVE * t;
-            if (4 * c < H) {
-                f32x4 a = acc[t];
-                const size_t off = (size_t)id * H + 4 * c;
-                if (accumulate) a += IO<DT_W>::load4(gW, off);
-                IO<DT_W>::store4(gW, off, a);
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 16 * u < np ? j0 + 16 * u : j0;
+#pragma unroll
+            for (int t = 0; t < PER; ++t) { const int c = lane + WAVE * t; v[u][t] = *reinterpret_cast<const f32x4*>(edge + (size_t)(2 * (b + 1 + j)) * H + 4 * (4 * c < H ? c : 0)); }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (j0 + 16 * u < np) {
+#pragma unroll
+                for (int t = 0; t < PER; ++t) acc[t] += v[u][t];
             }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) *reinterpret_cast<f32x4*>(&red[w][4 * (lane + WAVE * t)]) = acc[t];
+    __syncthreads();
+    if (w != 0) return;
+    const int64_t s1 = (b + 1) * EG_R < N ? (b + 1) * EG_R : N;
+    const long long id = sid[s1 - 1];
+    if (id < 0 || id >= V) return;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int c = lane + WAVE * t;
+        if (4 * c < H) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(&red[0][4 * c]);
+#pragma unroll
+            for (int q = 1; q < 16; ++q) a += *reinterpret_cast<const f32x4*>(&red[q][4 * c]);
+            const size_t off = (size_t)id * H + 4 * c;
+            if (accumulate) a += IO<DT_W>::load4(gW, off);
+            IO<DT_W>::store4(gW, off, a);
         }
     }
 }
@@ -1768,7 +1806,7 @@ int kvq_embed_grad(const void* g, const int64_t* perm, const int64_t* sorted_ids
     do {                                                                                                                       \
         hipLaunchKernelGGL((embed_grad_runs_kernel<DG, DW, P>), dim3((unsigned)nb), dim3(64), 0, st, g, perm, sorted_ids, N, H, V, \
                            gW, accumulate, edge, meta);                                                                        \
-        hipLaunchKernelGGL((embed_grad_edges_kernel<DW, P>), dim3((unsigned)nb), dim3(64), 0, st, sorted_ids, N, H, V, gW,      \
+        hipLaunchKernelGGL((embed_grad_edges_kernel<DW, P>), dim3((unsigned)nb), dim3(1024), 0, st, sorted_ids, N, H, V, gW,    \
                            accumulate, (const float*)edge, (const int*)meta, nb);                                             \
     } while (0)
 #define EG_PER(DG, DW)                                                                       \
