@@ -289,6 +289,15 @@ size_t kvq_embed_grad_workspace_bytes(int64_t N, int H);
 int kvq_embed_grad(const void* g, const int64_t* perm, const int64_t* sorted_ids, int64_t N, int H, int64_t V, int g_dtype,
                    void* gW, int w_dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+
+/* One Lloyd iteration's centroid update (the data-driven codebook initialiser of the reference runs
+ * scipy.cluster.vq.kmeans2(z, K, minit='points') on encoder outputs, models/shelgon3/vq_codebook_init_weights.py:85-101):
+ *     E_k <- mean of the rows z_n with idx_n == k  (f64 accumulation of per-chunk f32 sums, rows added in increasing n);
+ *     a cluster without rows keeps its centroid (kmeans2's missing='warn');  counts[K] (may be NULL) receives the cluster sizes.
+ * The assignment step of the iteration IS the hot kernel: kvq_vq_forward(z, E) -> idx.  ws: kvq_vq_workspace_bytes(N,K,D,1). */
+int kvq_kmeans_update(const void* z, const int64_t* idx, int64_t N, int K, int D, int io_dtype, float* E, int64_t* counts,
+                      void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -909,6 +909,24 @@ __global__ void vq_bwd_combine_kernel(BwdParams p) {
     p.g_E[(size_t)g * KD + e] = (p.beta * s) * a;
 }
 
+// k-means centroid update from the per-chunk cluster sums of vq_seg_sum_kernel<., 1>:  E_k <- mean of the points assigned to k;
+// a cluster without points keeps its centroid (scipy.cluster.vq.kmeans2, missing='warn').  Chunks are added in order.
+__global__ void kmeans_combine_kernel(const float* __restrict__ slab, const int* __restrict__ slab_cnt, int T, int K, int D,
+                                      float* __restrict__ E, long long* __restrict__ counts) {
+    const size_t KD = (size_t)K * D;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KD) return;
+    const int k = (int)(e / D);
+    double a = 0.0;
+    long long n = 0;
+    for (int t = 0; t < T; ++t) {
+        const int c = slab_cnt[(size_t)t * K + k];
+        if (c > 0) { a += (double)slab[(size_t)t * KD + e]; n += c; }
+    }
+    if (n > 0) E[e] = (float)(a / (double)n);
+    if (counts && e % D == 0) counts[k] = n;
+}
+
 // EMA apply (extension; textbook VQ-VAE EMA, see include/kvq.h)
 __global__ void vq_ema_counts_kernel(const int64_t* idx, int64_t N, int K, unsigned* cnt) {
     const int g = blockIdx.y;
@@ -1242,6 +1260,31 @@ int kvq_vq_ema_update(const void* z, const int64_t* idx, int64_t N, int K, int D
     hipLaunchKernelGGL(vq_ema_apply_kernel, dim3((unsigned)((KD + 255) / 256), (unsigned)G), dim3(256), 0, st, p.slab, p.slab_cnt, p.T, K, D,
                        decay, eps, ema_n, tot, ema_m, E);
     return check_launch("vq_ema_update");
+}
+
+int kvq_kmeans_update(const void* z, const int64_t* idx, int64_t N, int K, int D, int io_dtype, float* E, int64_t* counts,
+                      void* ws, size_t ws_bytes, void* stream) {
+    KVQ_REQUIRE(z && idx && E, "kvq_kmeans_update: null pointer argument");
+    KVQ_REQUIRE(N > 0 && K > 0 && D > 0, "kvq_kmeans_update: sizes must be positive");
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "kvq_kmeans_update: unsupported io dtype %d", io_dtype);
+    const WsLayout l = ws_layout(N, K, D, 1);
+    if (!ws || ws_bytes < l.total) return fail(KVQ_E_WORKSPACE, "kvq_kmeans_update: workspace %zu < %zu bytes", ws_bytes, l.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)ws;
+    BwdParams p;
+    p.z = z; p.E = nullptr; p.idx = idx; p.g_zq = nullptr; p.g_loss = nullptr; p.g_z = nullptr; p.g_E = nullptr;
+    p.slab = (float*)(w + l.slab);
+    p.N = N; p.K = K; p.D = D; p.T = pick_T(N, K, D); p.chunk = chunk_of(N, p.T); p.beta = 0.f;
+    p.slab_cnt = (int*)(w + l.slab_cnt);
+    dim3 grid((unsigned)K, (unsigned)p.T, 1u);
+    if (io_dtype == KVQ_F32) hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_F32, 1>), grid, dim3(SEG_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((vq_seg_sum_kernel<KVQ_BF16, 1>), grid, dim3(SEG_THREADS), 0, st, p);
+    int rc = check_launch("vq_seg_sum_kernel");
+    if (rc) return rc;
+    const size_t KD = (size_t)K * D;
+    hipLaunchKernelGGL(kmeans_combine_kernel, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0, st, p.slab, p.slab_cnt, p.T, K, D, E,
+                       (long long*)counts);
+    return check_launch("kmeans_combine_kernel");
 }
 
 int kvq_vq_one_hot(const int64_t* idx, int64_t N, int K, float* enc, void* stream) {

@@ -145,6 +145,46 @@ def vq_ema_update(z, idx, ema_n, ema_m, E, decay: float, eps: float = 1e-5):
                               ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_ema_update")
 
 
+def kmeans_update(z: torch.Tensor, idx: torch.Tensor, E: torch.Tensor):
+    """In place: E[k] <- mean of z[idx == k] (clusters without points keep their centroid).  Returns the cluster sizes [K] int64."""
+    require_gpu(z, idx, E)
+    N, D = z.shape
+    K = E.shape[0]
+    l = lib()
+    counts = torch.empty(K, dtype=torch.int64, device=z.device)
+    ws = _workspace(z.device, l.kvq_vq_workspace_bytes(N, K, D, 1))
+    check(l.kvq_kmeans_update(z.data_ptr(), idx.data_ptr(), N, K, D, io_dtype_of(z), E.data_ptr(), counts.data_ptr(),
+                              ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_kmeans_update")
+    return counts
+
+
+def kmeans2_points(z: torch.Tensor, k: int, iters: int = 10, init_indices=None, generator=None):
+    """Data-driven codebook initialisation on the GPU: the algorithm of `scipy.cluster.vq.kmeans2(z, k, iter=iters,
+    minit='points', missing='warn')`, which the reference runs on the CPU (models/shelgon3/vq_codebook_init_weights.py:85-101).
+
+    z [N, D] (f32 or bf16, on the GPU).  Initial centroids = k distinct rows of z (`init_indices`, or drawn with `generator`);
+    every iteration assigns each row to its nearest centroid with the VQ arg-min kernel (kvq_vq_forward) and moves every
+    non-empty cluster to the mean of its rows.  Returns (codebook [k, D] f32, labels [N] int64 of the LAST assignment), like
+    kmeans2.  Raises KvqError for bad arguments; nothing runs on the CPU."""
+    require_gpu(z)
+    if z.dim() != 2 or k < 1 or k > z.shape[0] or iters < 1:
+        raise _ffi.KvqError(f"kmeans2_points: need z[N,D], 1 <= k <= N, iters >= 1 (got {tuple(z.shape)}, k={k}, iters={iters})")
+    z = z.contiguous()
+    N = z.shape[0]
+    if init_indices is None:
+        init_indices = torch.randperm(N, generator=generator)[:k]
+    init_indices = torch.as_tensor(init_indices, dtype=torch.int64, device=z.device)
+    if init_indices.numel() != k or init_indices.unique().numel() != k:
+        raise _ffi.KvqError("kmeans2_points: init_indices must be k distinct row numbers")
+    E = z[init_indices].float().contiguous()
+    labels = None
+    with torch.no_grad():
+        for _ in range(iters):
+            _loss, _zq, _perp, labels, _cnt = vector_quantize(z, E, 0.0)
+            kmeans_update(z, labels, E)
+    return E, labels
+
+
 class _FusedCE(torch.autograd.Function):
     """logits[N,V], target[N] -> loss (mean CE), acc (token accuracy), pred[N].  Backward overwrites `logits`
     with its gradient in place when `inplace_backward` (saves N*V elements; the logits are dead by then)."""

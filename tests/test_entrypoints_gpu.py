@@ -67,3 +67,30 @@ def test_bagon_main_end_to_end(tmp_path):
     assert conf["model_mode"] == "dec-head-ft" and conf["n_params"]["encoder"]["n_trainable_params"] == 0
     logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
     assert any("test/loss_recon" in l for l in logs)
+
+
+def test_codebook_init_script_feeds_shelgon_main(tmp_path):
+    """models/shelgon3/vq_codebook_init_weights.py (GPU k-means on encoder outputs) writes the reference's file format, and
+    shelgon3/main.py starts from it (VQ_CODEBOOK_INIT_VALUES_PATH)."""
+    data = str(tmp_path / "data")
+    common = lambda d: {
+        "KVQ_SENTENCES_PATH": repr(d + "/dSentences_sentences_clean.npy"),
+        "KVQ_LATENT_CLASSES_LABELS_PATH": repr(d + "/dSentences_latent_classes_labels_clean.npy"),
+        "KVQ_LATENT_CLASSES_ONE_HOT_PATH": repr(d + "/dSentences_latent_classes_one_hot_clean.npy"),
+        "KVQ_VQ_N_E": "9", "KVQ_VQ_E_DIM": "128"}                                                   # N_E = 9 as in the reference script
+    env = dict(os.environ)
+    env.update({"PYTHONPATH": PKG, "KVQ_SYNTHETIC_SENTENCES": "640", "KVQ_TOKENIZED_SENTENCE_MAX_LENGTH": "12",
+                "KVQ_ENCODER_MODEL_NAME": "'kvq-bert-tiny'", "KVQ_DECODER_MODEL_NAME": "'kvq-bert-tiny'",
+                "KVQ_CODEBOOK_INIT_OUT": str(tmp_path / "init.pth")})
+    env.update(common(data))
+    r = subprocess.run([sys.executable, os.path.join(PKG, "models/shelgon3/vq_codebook_init_weights.py")], env=env, cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    blob = torch.load(str(tmp_path / "init.pth"), map_location="cpu")
+    assert set(blob) == {"codebook_init_values", "encoder_model_name", "decoder_model_name", "tokenizer_name"}     # reference :104-111
+    cb = blob["codebook_init_values"]
+    assert cb.shape == (9, 128) and cb.dtype == torch.float32 and torch.isfinite(cb).all() and cb.unique(dim=0).shape[0] == 9
+    run = _run("models/shelgon3/main.py", tmp_path, lambda d: dict(common(d), KVQ_N_EPOCHS="1",
+                                                                   KVQ_VQ_CODEBOOK_INIT_VALUES_PATH=repr(str(tmp_path / "init.pth"))))
+    conf = json.load(open(run + "/run_conf.json"))
+    assert conf["vq_n_e"] == 9 and conf["vq_codebook_init_values_path"].endswith("init.pth")

@@ -281,3 +281,43 @@ def test_collapsed_codebook(kvq, N, K, D):
     gz, gE = O.vq_backward(z, E, got["idx"], g, 1.3, 0.25)
     np.testing.assert_allclose(got["grad_z"], gz, rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(got["grad_E"], gE, rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,K,D", [(4096, 9, 768), (3000, 64, 128), (513, 5, 40)])
+def test_kmeans2_points_matches_scipy(N, K, D, dtype):
+    """GPU k-means (VQ arg-min kernel + kvq_kmeans_update) vs scipy.cluster.vq.kmeans2 -- the routine the reference calls
+    (vq_codebook_init_weights.py:91) -- started from the same points: same labels, same centroids, empty clusters kept."""
+    from scipy.cluster.vq import kmeans2
+    from kvq import functional as KF
+    rng = np.random.default_rng(N + K)
+    centers = rng.normal(size=(K, D)).astype(np.float32) * 3
+    data = (centers[rng.integers(0, K, size=N)] + rng.normal(size=(N, D)).astype(np.float32))
+    z = torch.from_numpy(data).cuda().to(dtype)
+    data = z.float().cpu().numpy()                       # cluster exactly what the GPU sees
+    init = rng.choice(N, size=K, replace=False)
+    cb_ref, lab_ref = kmeans2(data.astype(np.float64), data[init].astype(np.float64), iter=10, minit="matrix", missing="warn")
+    cb, lab = KF.kmeans2_points(z, K, iters=10, init_indices=torch.from_numpy(init))
+    assert cb.dtype == torch.float32 and lab.dtype == torch.int64 and lab.shape == (N,)
+    agree = (lab.cpu().numpy() == lab_ref).mean()
+    assert agree > 0.999, agree                          # a point on a bisector may round either way
+    np.testing.assert_allclose(cb.cpu().numpy(), cb_ref, rtol=2e-3, atol=2e-3)
+
+
+def test_kmeans_update_keeps_empty_clusters_and_counts():
+    from kvq import functional as KF
+    torch.manual_seed(0)
+    z = torch.randn(1000, 64, device="cuda")
+    E = torch.randn(4, 64, device="cuda")
+    E0 = E.clone()
+    idx = torch.randint(0, 3, (1000,), device="cuda")     # cluster 3 never used
+    counts = KF.kmeans_update(z, idx, E)
+    assert counts.tolist() == [int((idx == k).sum()) for k in range(4)] and counts[3] == 0
+    assert torch.equal(E[3], E0[3])
+    for k in range(3):
+        torch.testing.assert_close(E[k], z[idx == k].double().mean(0).float(), rtol=1e-5, atol=1e-6)
+    from kvq._ffi import KvqError
+    with pytest.raises(KvqError):
+        KF.kmeans2_points(z, 2000)
+    with pytest.raises(KvqError):
+        KF.kmeans2_points(z.cpu(), 4)
