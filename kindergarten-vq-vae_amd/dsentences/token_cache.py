@@ -1,0 +1,82 @@
+"""Pre-tokenised split resident in device memory -- SURVEY.md §8(f) rank 3 (host input pipeline).
+
+The reference tokenises every batch in Python inside the step (`models/shelgon3/Trainer.py:82-84`) and materialises the epoch
+with `list(dl_train)` (`:314`); at > 10 k sentences/s that host work is longer than the GPU step.  Here a split is tokenised
+ONCE (same tokenizer call: padding='max_length', max_length, add_special_tokens), kept as one [M, L] int64 tensor -- the whole
+576 k-sentence corpus at L = 32 is 147 MB, a rounding error of 288 GB of HBM -- and every batch is an index_select on the
+device: no tokenizer, no collate, no H2D copy in the step.  Batches have the layout `Trainer.tokenize_batch` already accepts
+({"input_ids", "attention_mask"}), so `step()` / `train()` / `test()` are unchanged.
+"""
+from typing import Iterator, Optional, Sequence
+
+import torch
+
+
+class TokenCache:
+    def __init__(self, sentences: Sequence[str], tokenizer, max_length: int, add_special_tokens: bool = False,
+                 device="cpu", chunk: int = 16384):
+        parts = []
+        for i in range(0, len(sentences), chunk):
+            tok = tokenizer(list(sentences[i:i + chunk]), return_tensors="pt", padding="max_length", max_length=max_length,
+                            truncation=True, add_special_tokens=add_special_tokens)
+            parts.append(tok.input_ids.to(torch.int64))
+        self.pad_id = int(getattr(tokenizer, "pad_token_id", 0) or 0)
+        ids = torch.cat(parts) if parts else torch.empty((0, max_length), dtype=torch.int64)
+        if ids.shape[1] != max_length:
+            raise ValueError(f"tokenizer returned rows of {ids.shape[1]} tokens, expected max_length={max_length}")
+        self.input_ids = ids.to(device)                               # [M, L], stays on the device
+        self.attention_mask = (self.input_ids != self.pad_id).to(torch.int64)
+        self.device = self.input_ids.device
+
+    def __len__(self) -> int:
+        return int(self.input_ids.shape[0])
+
+    def batch(self, index: torch.Tensor) -> dict:
+        index = index.to(self.device)
+        return {"input_ids": self.input_ids.index_select(0, index), "attention_mask": self.attention_mask.index_select(0, index)}
+
+    def loader(self, batch_size: int, shuffle: bool, seed: int = 0, drop_last: bool = False, rank: int = 0, world: int = 1):
+        return TokenCacheLoader(self, batch_size, shuffle, seed, drop_last, rank, world)
+
+
+class TokenCacheLoader:
+    """Re-iterable like a DataLoader: len() = batches per epoch, a fresh permutation per epoch (seed + epoch).
+    With world > 1 every rank takes an equal, disjoint slice of the (common) permutation; the tail that does not divide is dropped."""
+
+    def __init__(self, cache: TokenCache, batch_size: int, shuffle: bool, seed: int = 0, drop_last: bool = False,
+                 rank: int = 0, world: int = 1):
+        if batch_size < 1 or not (0 <= rank < world):
+            raise ValueError("TokenCacheLoader: bad batch_size / rank / world")
+        self.cache, self.batch_size, self.shuffle, self.seed = cache, int(batch_size), bool(shuffle), int(seed)
+        self.drop_last, self.rank, self.world = bool(drop_last or world > 1), int(rank), int(world)
+        self.epoch = 0
+
+    def _per_rank(self) -> int:
+        return len(self.cache) // self.world if self.world > 1 else len(self.cache)
+
+    def __len__(self) -> int:
+        n = self._per_rank()
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self) -> Iterator[dict]:
+        m = len(self.cache)
+        if self.shuffle:
+            order = torch.randperm(m, generator=torch.Generator().manual_seed(self.seed + self.epoch))
+        else:
+            order = torch.arange(m)
+        self.epoch += 1
+        n = self._per_rank()
+        mine = order[self.rank * n:(self.rank + 1) * n].to(self.cache.device)
+        for i in range(len(self)):
+            yield self.cache.batch(mine[i * self.batch_size:(i + 1) * self.batch_size])
+
+
+def cache_of_split(split, tokenizer, max_length: int, add_special_tokens: bool, device) -> TokenCache:
+    """TokenCache of a torch.utils.data.Subset / dataset whose items carry a "sentence" (random_split output of the mains)."""
+    if hasattr(split, "dataset") and hasattr(split, "indices") and hasattr(split.dataset, "sentences"):
+        sentences = [split.dataset.sentences[i] for i in split.indices]
+    elif hasattr(split, "sentences"):
+        sentences = list(split.sentences)
+    else:
+        sentences = [split[i]["sentence"] for i in range(len(split))]
+    return TokenCache(sentences, tokenizer, max_length, add_special_tokens, device)

@@ -19,6 +19,7 @@ VAL_SPLIT_PCT = 0.2
 BATCH_SIZE = 256                     # per GPU
 NUM_WORKERS = 0
 PIN_MEMORY = True
+TOKEN_CACHE = True              # tokenise every split once, keep it in HBM, batches = device index_select (dsentences/token_cache.py)
 
 # --- model ----------------------------------------------------------------------------------------------------------
 ENCODER_MODEL_NAME = "bert-base-uncased"

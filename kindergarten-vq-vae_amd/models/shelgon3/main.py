@@ -30,6 +30,7 @@ from torch.utils.data.distributed import DistributedSampler  # noqa: E402
 from common.consts import *  # noqa: E402,F401,F403
 from dsentences.dataset import dSentencesDataset  # noqa: E402
 from dsentences.synthetic import write_corpus  # noqa: E402
+from dsentences.token_cache import cache_of_split  # noqa: E402
 from kvq import ddp  # noqa: E402
 from kvq.engine import TrainEngine  # noqa: E402
 from kvq.runlog import init_run  # noqa: E402
@@ -83,6 +84,13 @@ def main():
         model.model_params_summary_print()
 
     tokenizer = load_tokenizer(TOKENIZER_NAME)
+    if TOKEN_CACHE:
+        # every split tokenised once and kept in HBM; a batch is an index_select on the device (no per-step tokenizer / H2D)
+        caches = [cache_of_split(sp, tokenizer, TOKENIZED_SENTENCE_MAX_LENGTH, TOKENIZER_ADD_SPECIAL_TOKENS, device)
+                  for sp in (ds_train, ds_val, ds_test)]
+        dl_train = caches[0].loader(BATCH_SIZE, True, seed=DS_GEN_SEED, rank=rank, world=world)
+        dl_val = caches[1].loader(BATCH_SIZE, False, rank=rank, world=world)
+        dl_test = caches[2].loader(BATCH_SIZE, False, rank=rank, world=world)
     opt = Adam(params=[p for p in model.parameters()], lr=LR, weight_decay=WEIGHT_DECAY, amsgrad=AMSGRAD, fused=True)
     lr_sched = MultiStepLR(optimizer=opt, milestones=MILESTONES, gamma=GAMMA) if LR_SCHEDULER == "MultiStepLR" else None
     engine = grad_sync = None

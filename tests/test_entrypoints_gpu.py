@@ -38,8 +38,10 @@ def test_shelgon_main_end_to_end(tmp_path, use_engine):
         "KVQ_SENTENCES_PATH": repr(d + "/dSentences_sentences_clean.npy"),
         "KVQ_LATENT_CLASSES_LABELS_PATH": repr(d + "/dSentences_latent_classes_labels_clean.npy"),
         "KVQ_LATENT_CLASSES_ONE_HOT_PATH": repr(d + "/dSentences_latent_classes_one_hot_clean.npy"),
-        "KVQ_VQ_N_E": "32", "KVQ_VQ_E_DIM": "128", "KVQ_USE_ENGINE": str(use_engine)})
+        "KVQ_VQ_N_E": "32", "KVQ_VQ_E_DIM": "128", "KVQ_USE_ENGINE": str(use_engine),
+        "KVQ_TOKEN_CACHE": str(use_engine)})          # engine run: splits pre-tokenised in HBM; autograd run: DataLoader + per-step tokenizer
     conf = json.load(open(run + "/run_conf.json"))
+    assert conf["token_cache"] == use_engine
     assert conf["vq_n_e"] == 32 and conf["encoder_model_name"] == "kvq-bert-tiny" and "n_params" in conf
     ckpt = torch.load(run + "/shelgon_ckpt_loss_recon_val_best.pth", map_location="cpu")
     assert set(ckpt) == {"model_state_dict", "encoder_state_dict", "decoder_state_dict"}         # Trainer.py:240-249
