@@ -298,6 +298,22 @@ int kvq_embed_grad(const void* g, const int64_t* perm, const int64_t* sorted_ids
 int kvq_kmeans_update(const void* z, const int64_t* idx, int64_t N, int K, int D, int io_dtype, float* E, int64_t* counts,
                       void* ws, size_t ws_bytes, void* stream);
 
+
+/* ---- Gumbel-softmax quantiser (the reference's other VQ_MODE, models/shelgon3/GumbelQuantizer.py:43-83) ---------------------
+ * Row-wise part of GumbelQuantizer.forward between its two GEMMs (logits = proj(z), z_q = y . embed):
+ *   y_soft = softmax((logits + g) / tau) with g ~ Gumbel(0,1);  ind = argmax(y_soft) (first maximum);
+ *   y = y_soft, or (hard != 0) fl(fl(one_hot(ind) - y_soft) + y_soft): torch.nn.functional.gumbel_softmax's return value;
+ *   kl_row[n] = sum_k q log(q K + 1e-10), q = softmax(logits)   (diff = kld_scale * mean_n kl_row, :73).
+ * logits, y [N,K] io_dtype; y_soft [N,K] f32 (kept for backward; may be NULL), ind [N] int64, kl_row [N] f32.
+ * noise [N,K] f32 supplies g explicitly (parity tests against torch's generator); NULL draws it from Philox4x32-10
+ * (seed, site; plus the device step count when kvq_set_seed_offset is active).  K <= 1024.
+ * Backward: g_logits = y_soft (g_y - <y_soft,g_y>) / tau  +  g_diff kld_scale/N * q (L - <q,L>),
+ *   L = log(q K + 1e-10) + q K / (q K + 1e-10); g_y may be NULL (no gradient through y), g_diff NULL means 1. */
+int kvq_gumbel_forward(const void* logits, const float* noise, int64_t N, int K, float tau, int hard, uint64_t seed, uint32_t site,
+                       int io_dtype, void* y, float* y_soft, int64_t* ind, float* kl_row, void* stream);
+int kvq_gumbel_backward(const void* logits, const float* y_soft, const void* g_y, const float* g_diff, int64_t N, int K, float tau,
+                        float kld_scale, int io_dtype, void* g_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

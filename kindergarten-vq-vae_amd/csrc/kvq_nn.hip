@@ -785,6 +785,148 @@ __global__ __launch_bounds__(1024) void embed_grad_edges_kernel(const int64_t* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Gumbel-softmax quantiser rows (models/shelgon3/GumbelQuantizer.py:56-76; torch.nn.functional.gumbel_softmax):
+//   t = (logits + g) / tau,  g = -log(Exp(1) sample);  y_soft = softmax(t);  ind = argmax(y_soft) (first maximum);
+//   y = y_soft, or with `hard`  fl(fl(one_hot(ind) - y_soft) + y_soft)  (the straight-through value torch returns);
+//   kl_row = sum_k q_k log(q_k K + 1e-10),  q = softmax(logits).
+// One wave per token row, K <= 64 * PER.  g comes from `noise` [N,K] f32 when given (parity tests), else from Philox
+// (seed, site, element index / 4; two uniforms -> g = -log(-log u)).  All arithmetic f32.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, WAVE));
+    return v;
+}
+__device__ __forceinline__ float gumbel_from_bits(unsigned b) {
+    const float u = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+    return -__logf(-__logf(u));
+}
+
+template <int DT, int PER>
+__global__ __launch_bounds__(256) void gumbel_fwd_kernel(const void* __restrict__ logits, const float* __restrict__ noise,
+                                                          int64_t N, int K, float inv_tau, int hard, unsigned long long seed,
+                                                          const unsigned long long* __restrict__ seed_off, unsigned site,
+                                                          void* __restrict__ y_out, float* __restrict__ y_soft,
+                                                          int64_t* __restrict__ ind, float* __restrict__ kl_row) {
+    if (seed_off) seed += *seed_off;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    float l[PER], t[PER];
+    float tmax = -INFINITY, lmax = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int k = lane + WAVE * u;
+        l[u] = -INFINITY; t[u] = -INFINITY;
+        if (k < K) {
+            const size_t e = (size_t)row * K + k;
+            l[u] = IO<DT>::load1(logits, e);
+            float g;
+            if (noise) g = noise[e];
+            else {
+                const U4 b = drop_bits(seed, site, e >> 2);
+                const unsigned w4[4] = {b.x, b.y, b.z, b.w};
+                g = gumbel_from_bits(w4[e & 3]);
+            }
+            t[u] = (l[u] + g) * inv_tau;
+            tmax = fmaxf(tmax, t[u]); lmax = fmaxf(lmax, l[u]);
+        }
+    }
+    tmax = wave_max_f32(tmax); lmax = wave_max_f32(lmax);
+    float ts = 0.f, ls = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const bool in = lane + WAVE * u < K;
+        t[u] = in ? __expf(t[u] - tmax) : 0.f;
+        l[u] = in ? __expf(l[u] - lmax) : 0.f;
+        ts += t[u]; ls += l[u];
+    }
+    ts = wave_sum_f32(ts); ls = wave_sum_f32(ls);
+    const float tinv = 1.0f / ts, linv = 1.0f / ls;
+    // arg-max of y_soft: largest value, lowest index on ties
+    float best = -1.f; int bi = 0x7fffffff;
+    float kl = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int k = lane + WAVE * u;
+        if (k < K) {
+            t[u] *= tinv;
+            if (t[u] > best) { best = t[u]; bi = k; }
+            const float q = l[u] * linv;
+            kl += q * __logf(q * (float)K + 1e-10f);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ob = __shfl_xor(best, m, WAVE);
+        const int oi = __shfl_xor(bi, m, WAVE);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    kl = wave_sum_f32(kl);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int k = lane + WAVE * u;
+        if (k < K) {
+            const size_t e = (size_t)row * K + k;
+            if (y_soft) y_soft[e] = t[u];
+            float y = t[u];
+            if (hard) { const float h = k == bi ? 1.0f : 0.0f; y = (h - t[u]) + t[u]; }
+            IO<DT>::store1(y_out, e, y);
+        }
+    }
+    if (lane == 0) { ind[row] = bi; kl_row[row] = kl; }
+}
+
+// g_logits = (1/tau) y (g_y - <y, g_y>)  +  c q (L - <q, L>),   L_k = log(q_k K + eps) + q_k K / (q_k K + eps),
+// y = y_soft (the straight-through estimator passes the gradient of the soft sample), c = g_diff * kld_scale / N
+template <int DT, int PER>
+__global__ __launch_bounds__(256) void gumbel_bwd_kernel(const void* __restrict__ logits, const float* __restrict__ y_soft,
+                                                          const void* __restrict__ g_y, const float* __restrict__ g_diff,
+                                                          int64_t N, int K, float inv_tau, float kld_scale,
+                                                          void* __restrict__ g_logits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float c = (g_diff ? g_diff[0] : 1.0f) * kld_scale / (float)N;
+    float y[PER], gy[PER], l[PER];
+    float lmax = -INFINITY, dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int k = lane + WAVE * u;
+        y[u] = 0.f; gy[u] = 0.f; l[u] = -INFINITY;
+        if (k < K) {
+            const size_t e = (size_t)row * K + k;
+            y[u] = y_soft[e];
+            gy[u] = g_y ? IO<DT>::load1(g_y, e) : 0.f;
+            l[u] = IO<DT>::load1(logits, e);
+            lmax = fmaxf(lmax, l[u]);
+            dot += y[u] * gy[u];
+        }
+    }
+    lmax = wave_max_f32(lmax);
+    dot = wave_sum_f32(dot);
+    float ls = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { l[u] = lane + WAVE * u < K ? __expf(l[u] - lmax) : 0.f; ls += l[u]; }
+    ls = wave_sum_f32(ls);
+    const float linv = 1.0f / ls;
+    float L[PER], qL = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        l[u] *= linv;                                                    // q
+        const float qk = l[u] * (float)K;
+        L[u] = __logf(qk + 1e-10f) + qk / (qk + 1e-10f);
+        qL += l[u] * L[u];
+    }
+    qL = wave_sum_f32(qL);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int k = lane + WAVE * u;
+        if (k < K) IO<DT>::store1(g_logits, (size_t)row * K + k, inv_tau * y[u] * (gy[u] - dot) + c * l[u] * (L[u] - qL));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Attention for short sentences: S_q, S_k <= 32, head dim 64.  One wave per (sentence, head).
 //   lane = (query i = lane & 31, half h = lane >> 5).  QK^T: the lane scores its query against keys 16h..16h+15
 //   (K rows are LDS broadcasts); softmax row = 16 in-lane values + one exchange with lane^32; PV: the lane produces
@@ -1822,6 +1964,48 @@ int kvq_embed_grad(const void* g, const int64_t* perm, const int64_t* sorted_ids
 #undef EG_LAUNCH
     return check_launch("embed_grad_kernel");
 }
+
+#define GUMBEL_DISPATCH(KERNEL, ...)                                                                                       \
+    do {                                                                                                                   \
+        const int per = (K + WAVE - 1) / WAVE;                                                                             \
+        dim3 grid((unsigned)((N + 3) / 4));                                                                                \
+        if (io_dtype == KVQ_F32) {                                                                                         \
+            if (per <= 1) hipLaunchKernelGGL((KERNEL<KVQ_F32, 1>), grid, dim3(256), 0, st, __VA_ARGS__);                   \
+            else if (per <= 2) hipLaunchKernelGGL((KERNEL<KVQ_F32, 2>), grid, dim3(256), 0, st, __VA_ARGS__);              \
+            else if (per <= 4) hipLaunchKernelGGL((KERNEL<KVQ_F32, 4>), grid, dim3(256), 0, st, __VA_ARGS__);              \
+            else if (per <= 8) hipLaunchKernelGGL((KERNEL<KVQ_F32, 8>), grid, dim3(256), 0, st, __VA_ARGS__);              \
+            else hipLaunchKernelGGL((KERNEL<KVQ_F32, 16>), grid, dim3(256), 0, st, __VA_ARGS__);                           \
+        } else {                                                                                                           \
+            if (per <= 1) hipLaunchKernelGGL((KERNEL<KVQ_BF16, 1>), grid, dim3(256), 0, st, __VA_ARGS__);                  \
+            else if (per <= 2) hipLaunchKernelGGL((KERNEL<KVQ_BF16, 2>), grid, dim3(256), 0, st, __VA_ARGS__);             \
+            else if (per <= 4) hipLaunchKernelGGL((KERNEL<KVQ_BF16, 4>), grid, dim3(256), 0, st, __VA_ARGS__);             \
+            else if (per <= 8) hipLaunchKernelGGL((KERNEL<KVQ_BF16, 8>), grid, dim3(256), 0, st, __VA_ARGS__);             \
+            else hipLaunchKernelGGL((KERNEL<KVQ_BF16, 16>), grid, dim3(256), 0, st, __VA_ARGS__);                          \
+        }                                                                                                                  \
+    } while (0)
+
+int kvq_gumbel_forward(const void* logits, const float* noise, int64_t N, int K, float tau, int hard, uint64_t seed, uint32_t site,
+                       int io_dtype, void* y, float* y_soft, int64_t* ind, float* kl_row, void* stream) {
+    KVQ_REQUIRE(logits && y && ind && kl_row && N > 0, "kvq_gumbel_forward: bad argument");
+    KVQ_REQUIRE(K >= 1 && K <= 1024, "kvq_gumbel_forward: K=%d unsupported (1..1024 codes)", K);
+    KVQ_REQUIRE(tau > 0.f, "kvq_gumbel_forward: temperature must be positive");
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
+    hipStream_t st = (hipStream_t)stream;
+    GUMBEL_DISPATCH(gumbel_fwd_kernel, logits, noise, N, K, 1.0f / tau, hard, (unsigned long long)seed, g_seed_off, site, y, y_soft, ind, kl_row);
+    return check_launch("gumbel_fwd_kernel");
+}
+
+int kvq_gumbel_backward(const void* logits, const float* y_soft, const void* g_y, const float* g_diff, int64_t N, int K, float tau,
+                        float kld_scale, int io_dtype, void* g_logits, void* stream) {
+    KVQ_REQUIRE(logits && y_soft && g_logits && N > 0, "kvq_gumbel_backward: bad argument");
+    KVQ_REQUIRE(K >= 1 && K <= 1024, "kvq_gumbel_backward: K=%d unsupported (1..1024 codes)", K);
+    KVQ_REQUIRE(tau > 0.f, "kvq_gumbel_backward: temperature must be positive");
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
+    hipStream_t st = (hipStream_t)stream;
+    GUMBEL_DISPATCH(gumbel_bwd_kernel, logits, y_soft, g_y, g_diff, N, K, 1.0f / tau, kld_scale, g_logits);
+    return check_launch("gumbel_bwd_kernel");
+}
+#undef GUMBEL_DISPATCH
 
 int kvq_set_seed_offset(const void* step_state) {
     g_seed_off = reinterpret_cast<const unsigned long long*>(step_state);

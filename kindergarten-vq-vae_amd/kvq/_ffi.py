@@ -42,6 +42,8 @@ SIGNATURES = {
     "kvq_vq_debug_distances": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),
     "kvq_vq_ema_update": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kvq_kmeans_update": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "kvq_gumbel_forward": (_int, [_vp, _vp, _i64, _int, _f32, _int, C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp]),
+    "kvq_gumbel_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, _int, _vp, _vp]),
     "kvq_ce_forward": (_int, [_vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kvq_ce_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp]),
     "kvq_dropout_residual_ln_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp]),

@@ -212,6 +212,9 @@ class TrainEngine:
         self.dtype = model.compute_dtype
         self.io = 1 if self.dtype == torch.bfloat16 else 0
         self.has_vq = hasattr(model, "vector_quantizer")
+        if self.has_vq and type(model.vector_quantizer).__name__ != "VectorQuantizer":
+            raise KvqError(f"TrainEngine schedules the VectorQuantizer step; {type(model.vector_quantizer).__name__} models train "
+                           f"through Shelgon.forward_loss + torch autograd (USE_ENGINE = False)")
         enc, dec = model.encoder, model.decoder
         self.ecfg, self.dcfg = enc.config, dec.config
         if self.ecfg.hidden_size // self.ecfg.num_attention_heads != 64:
@@ -804,7 +807,9 @@ class TrainEngine:
     def supports(model, seq_len: int) -> bool:
         """The engine covers BERT-shaped models with 64-wide heads and sentences of at most 32 tokens."""
         cfg = model.encoder.config
-        return cfg.hidden_size // cfg.num_attention_heads == 64 and seq_len <= 32 and cfg.hidden_size % 32 == 0
+        kind = type(getattr(model, "vector_quantizer", None)).__name__          # the Gumbel quantiser runs on the autograd path
+        return kind in ("VectorQuantizer", "NoneType") and cfg.hidden_size // cfg.num_attention_heads == 64 and seq_len <= 32 \
+            and cfg.hidden_size % 32 == 0
 
     def _train_step_eager(self, input_ids, attention_mask):
         out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True)

@@ -185,6 +185,54 @@ def kmeans2_points(z: torch.Tensor, k: int, iters: int = 10, init_indices=None, 
     return E, labels
 
 
+class _GumbelQuantize(torch.autograd.Function):
+    """logits [N,K] -> (y [N,K], diff (0-d), ind [N]); row-wise part of GumbelQuantizer.forward (kvq_gumbel_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, logits, tau, hard, kld_scale, noise, seed, site):
+        require_gpu(logits, noise)
+        logits = logits.contiguous()
+        N, K = logits.shape
+        dev = logits.device
+        y = torch.empty_like(logits)
+        y_soft = torch.empty((N, K), dtype=torch.float32, device=dev)
+        ind = torch.empty(N, dtype=torch.int64, device=dev)
+        kl_row = torch.empty(N, dtype=torch.float32, device=dev)
+        if noise is not None:
+            if noise.shape != logits.shape or noise.dtype != torch.float32:
+                raise _ffi.KvqError("gumbel_quantize: noise must be float32 with the shape of logits")
+            noise = noise.contiguous()
+        check(lib().kvq_gumbel_forward(logits.data_ptr(), _ptr(noise), N, K, float(tau), int(bool(hard)), int(seed), int(site),
+                                       io_dtype_of(logits), y.data_ptr(), y_soft.data_ptr(), ind.data_ptr(), kl_row.data_ptr(),
+                                       stream_ptr()), "kvq_gumbel_forward")
+        diff = kl_row.double().mean().float() * float(kld_scale)          # GumbelQuantizer.py:73 (.mean() over the B*S rows)
+        ctx.save_for_backward(logits, y_soft)
+        ctx.tau, ctx.kld_scale = float(tau), float(kld_scale)
+        ctx.mark_non_differentiable(ind)
+        return y, diff, ind
+
+    @staticmethod
+    def backward(ctx, g_y, g_diff, _g_ind):
+        logits, y_soft = ctx.saved_tensors
+        N, K = logits.shape
+        g_logits = torch.empty_like(logits)
+        gd = g_diff.reshape(1).float().contiguous() if g_diff is not None else torch.zeros(1, device=logits.device)
+        gy = g_y.contiguous().to(logits.dtype) if g_y is not None else None
+        check(lib().kvq_gumbel_backward(logits.data_ptr(), y_soft.data_ptr(), _ptr(gy), gd.data_ptr(), N, K, ctx.tau, ctx.kld_scale,
+                                        io_dtype_of(logits), g_logits.data_ptr(), stream_ptr()), "kvq_gumbel_backward")
+        return g_logits, None, None, None, None, None, None
+
+
+def gumbel_quantize(logits: torch.Tensor, tau: float, hard: bool, kld_scale: float, noise=None, seed: int = 0, site: int = 0):
+    """Gumbel-softmax sample over the last dim of logits [N,K] plus the KL-to-uniform term (GumbelQuantizer.py:56-76).
+
+    Returns (y, diff, ind): y the soft sample or, with `hard`, its straight-through one-hot; diff = kld_scale * mean_n
+    sum_k q log(q K + 1e-10); ind = argmax.  `noise` (float32 [N,K] Gumbel(0,1) samples) replaces the Philox stream."""
+    if logits.dim() != 2:
+        raise _ffi.KvqError(f"gumbel_quantize: logits must be [N, K], got {tuple(logits.shape)}")
+    return _GumbelQuantize.apply(logits, tau, hard, kld_scale, noise, seed, site)
+
+
 class _FusedCE(torch.autograd.Function):
     """logits[N,V], target[N] -> loss (mean CE), acc (token accuracy), pred[N].  Backward overwrites `logits`
     with its gradient in place when `inplace_backward` (saves N*V elements; the logits are dead by then)."""

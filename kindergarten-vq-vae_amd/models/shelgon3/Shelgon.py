@@ -44,8 +44,13 @@ class Shelgon(Bagon):
         if kind == "VectorQuantizer":
             vq_loss, z_q, perplexity, _enc, indices = self.vector_quantizer.forward(embeds.contiguous(), device)
             return vq_loss, z_q, perplexity, indices
-        raise ValueError(f"{kind} vector quantizer mode NOT supported. Supported modalities: VectorQuantizer "
-                         f"(GumbelQuantizer is outside this build's hot path, SURVEY.md §2.1 #7)")
+        if kind == "GumbelQuantizer":                                              # Shelgon.py:60-65
+            z_q, vq_loss, indices = self.vector_quantizer.forward(embeds, self.training)
+            # "not the actual perplexity computation, but still informative" (Shelgon.py:63): number of codes in use,
+            # counted on the device instead of through a .cpu() copy
+            perplexity = torch.unique(indices).numel()
+            return vq_loss, z_q.to(embeds.dtype), torch.tensor(float(perplexity), device=embeds.device), indices
+        raise ValueError(f"{kind} vector quantizer mode NOT supported. Supported modalities: VectorQuantizer, GumbelQuantizer")
 
     def forward(self, input_ids, attention_mask, device=None, is_training: bool = True):
         embeds = self.encode(input_ids, attention_mask)                            # Shelgon.py:52

@@ -37,6 +37,7 @@ from kvq.runlog import init_run  # noqa: E402
 from kvq.tokenizer import load_tokenizer  # noqa: E402
 from models.shelgon3.Shelgon import Shelgon  # noqa: E402
 from models.shelgon3.Trainer import test, train  # noqa: E402
+from models.shelgon3.GumbelQuantizer import GumbelQuantizer  # noqa: E402
 from models.shelgon3.VectorQuantizer import VectorQuantizer  # noqa: E402
 
 
@@ -67,11 +68,16 @@ def main():
                           shuffle=shuffle and sampler is None, sampler=sampler, drop_last=world > 1)
     dl_train, dl_val, dl_test = loader(ds_train, True), loader(ds_val, False), loader(ds_test, False)
 
-    if VQ_MODE != "VectorQuantizer":
-        raise ValueError(f"{VQ_MODE} vector quantizer mode NOT supported by this build. Supported: VectorQuantizer")
-    init = torch.load(VQ_CODEBOOK_INIT_VALUES_PATH)["codebook_init_values"] if VQ_CODEBOOK_INIT_VALUES_PATH else None
-    vector_quantizer = VectorQuantizer(n_e=VQ_N_E, e_dim=VQ_E_DIM, beta=VQ_BETA, vq_codebook_init_values=init)
-    vector_quantizer.materialize_min_encodings = False          # the model drops min_encodings (Shelgon.py:58)
+    if VQ_MODE == "VectorQuantizer":
+        init = torch.load(VQ_CODEBOOK_INIT_VALUES_PATH)["codebook_init_values"] if VQ_CODEBOOK_INIT_VALUES_PATH else None
+        vector_quantizer = VectorQuantizer(n_e=VQ_N_E, e_dim=VQ_E_DIM, beta=VQ_BETA, vq_codebook_init_values=init)
+        vector_quantizer.materialize_min_encodings = False          # the model drops min_encodings (Shelgon.py:58)
+    elif VQ_MODE == "GumbelQuantizer":                              # main.py:68-73
+        vector_quantizer = GumbelQuantizer(enc_out_size=ENC_OUT_SIZE, n_embed=VQ_N_E, embedding_dim=VQ_E_DIM,
+                                           temperature=VQ_TEMPERATURE, kl_div_scale=VQ_KL_DIV_SCALE,
+                                           straight_through=VQ_STRAIGHT_THROUGH)
+    else:
+        raise ValueError(f"{VQ_MODE} vector quantizer mode NOT supported. Supported modalities: VectorQuantizer, GumbelQuantizer")
 
     torch.manual_seed(0)                                          # same init on every rank
     model = Shelgon(encoder_model_name=ENCODER_MODEL_NAME, vector_quantizer=vector_quantizer,
@@ -94,7 +100,7 @@ def main():
     opt = Adam(params=[p for p in model.parameters()], lr=LR, weight_decay=WEIGHT_DECAY, amsgrad=AMSGRAD, fused=True)
     lr_sched = MultiStepLR(optimizer=opt, milestones=MILESTONES, gamma=GAMMA) if LR_SCHEDULER == "MultiStepLR" else None
     engine = grad_sync = None
-    if USE_ENGINE and TrainEngine.supports(model, TOKENIZED_SENTENCE_MAX_LENGTH):
+    if USE_ENGINE and VQ_MODE == "VectorQuantizer" and TrainEngine.supports(model, TOKENIZED_SENTENCE_MAX_LENGTH):
         # explicit forward/backward schedule on flat buffers (kvq/engine.py): owns Adam, the scheduler tick and the
         # RCCL gradient exchange; `opt` above is then only the reference-shaped handle recorded in run_conf.json
         engine = TrainEngine(model, lr=LR, weight_decay=WEIGHT_DECAY, amsgrad=AMSGRAD,

@@ -96,3 +96,18 @@ def test_codebook_init_script_feeds_shelgon_main(tmp_path):
                                                                    KVQ_VQ_CODEBOOK_INIT_VALUES_PATH=repr(str(tmp_path / "init.pth"))))
     conf = json.load(open(run + "/run_conf.json"))
     assert conf["vq_n_e"] == 9 and conf["vq_codebook_init_values_path"].endswith("init.pth")
+
+
+def test_shelgon_main_gumbel_mode(tmp_path):
+    """VQ_MODE = "GumbelQuantizer" (reference main.py:68-73): the run trains through the autograd path and writes the usual artefacts."""
+    run = _run("models/shelgon3/main.py", tmp_path, lambda d: {
+        "KVQ_SENTENCES_PATH": repr(d + "/dSentences_sentences_clean.npy"),
+        "KVQ_LATENT_CLASSES_LABELS_PATH": repr(d + "/dSentences_latent_classes_labels_clean.npy"),
+        "KVQ_LATENT_CLASSES_ONE_HOT_PATH": repr(d + "/dSentences_latent_classes_one_hot_clean.npy"),
+        "KVQ_VQ_MODE": "'GumbelQuantizer'", "KVQ_VQ_N_E": "16", "KVQ_VQ_E_DIM": "128", "KVQ_ENC_OUT_SIZE": "128", "KVQ_N_EPOCHS": "1"})
+    ckpt = torch.load(run + "/shelgon_ckpt_loss_recon_val_best.pth", map_location="cpu")
+    sd = ckpt["model_state_dict"]
+    assert sd["vector_quantizer.proj.weight"].shape == (16, 128, 1) and sd["vector_quantizer.embed.weight"].shape == (16, 128)
+    logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
+    perp = [l["train/metric_perp"] for l in logs if "train/metric_perp" in l]
+    assert perp and 1 <= perp[0] <= 16            # "perplexity" of this mode = number of codes in use (Shelgon.py:63-65)

@@ -117,3 +117,32 @@ def test_oracle_dot_order_is_documented_walk():
                         np.float32(np.float64(a[j]) * np.float64(b[j]) + np.float64(acc))
         got = lib.kvq_oracle_dot(a.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)), D)
         assert np.float32(got) == acc
+
+
+# ---- Gumbel quantiser: oracle/gumbel_oracle.py against the reference module's own outputs (tests/golden/gumbel_*.npz) ----------
+import glob as _glob
+import os as _os
+
+GUMBEL_CASES = sorted(_os.path.basename(p)[:-4] for p in _glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "gumbel_*.npz")))
+
+
+def _gumbel_case(name):
+    return dict(np.load(_os.path.join(_os.path.dirname(__file__), "golden", name + ".npz")))
+
+
+@pytest.mark.parametrize("name", GUMBEL_CASES)
+def test_gumbel_oracle_matches_reference(name):
+    from oracle import gumbel_oracle as GO
+    c = _gumbel_case(name)
+    hard = bool(c["straight_through"]) if bool(c["is_training"]) else True          # GumbelQuantizer.py:54
+    out = GO.forward(c["z"], c["W"], c["b"], c["E"], c["noise"], float(c["tau"]), hard, float(c["kld_scale"]))
+    assert np.array_equal(out["ind"], c["ind"])
+    np.testing.assert_allclose(out["z_q"], c["z_q"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["diff"], c["diff"], rtol=2e-5, atol=1e-9)
+    g = GO.forward_backward_torch(c["z"], c["W"], c["b"], c["E"], c["noise"], float(c["tau"]), hard, float(c["kld_scale"]), c["G"], float(c["c"]))
+    for k in ("grad_z", "grad_W", "grad_b", "grad_E"):
+        np.testing.assert_allclose(g[k], c[k], rtol=1e-3, atol=5e-5, err_msg=k)      # conv1d vs matmul summation order
+
+
+def test_gumbel_golden_set_is_complete():
+    assert len(GUMBEL_CASES) == 5 and "gumbel_eval" in GUMBEL_CASES
