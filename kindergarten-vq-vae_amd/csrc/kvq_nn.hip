@@ -539,6 +539,28 @@ __global__ __launch_bounds__(128) void gelu_bwd_bias_kernel(const void* __restri
 // Adam (torch.optim.Adam, coupled L2 weight decay, optional amsgrad) on flat buffers:
 //   p32 (master, f32), g (bf16 or f32), m, v (f32) [, vmax], shadow (bf16 copy of p32 for the next forward)
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam_update4(f32x4& pv, f32x4 gv, f32x4& mv, f32x4& vv, float* vmax4, float lr, float b1, float b2,
+                                             float eps, float wd, float bc1, float bc2_sqrt) {
+    gv += pv * wd;
+    mv = mv * b1 + gv * (1.0f - b1);
+    vv = vv * b2 + (gv * gv) * (1.0f - b2);
+    f32x4 den_src = vv;
+    if (vmax4) {
+        f32x4 vm = *reinterpret_cast<f32x4*>(vmax4);
+        vm.x = fmaxf(vm.x, vv.x); vm.y = fmaxf(vm.y, vv.y); vm.z = fmaxf(vm.z, vv.z); vm.w = fmaxf(vm.w, vv.w);
+        *reinterpret_cast<f32x4*>(vmax4) = vm;
+        den_src = vm;
+    }
+    f32x4 den;
+    den.x = sqrtf(den_src.x) / bc2_sqrt + eps; den.y = sqrtf(den_src.y) / bc2_sqrt + eps;
+    den.z = sqrtf(den_src.z) / bc2_sqrt + eps; den.w = sqrtf(den_src.w) / bc2_sqrt + eps;
+    const float step = lr / bc1;
+    pv.x -= step * (mv.x / den.x); pv.y -= step * (mv.y / den.y);
+    pv.z -= step * (mv.z / den.z); pv.w -= step * (mv.w / den.w);
+}
+
+// 8 parameters per thread and pass: every array moves in 16-byte accesses (the bf16 gradient and shadow included), two
+// independent 4-element updates in flight.  n8 = n / 8 chunks; a tail of 4 (n % 8 == 4) is handled by the last thread.
 template <int DT_G>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, float* __restrict__ vmax,
@@ -546,31 +568,26 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                     float b2, float eps, float wd, float bc1, float bc2_sqrt,
                                                     float grad_scale, const float* __restrict__ hyper) {
     if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }     // device-resident step state (kvq_step_state_advance)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 pv = *reinterpret_cast<f32x4*>(p + 4 * i);
-        f32x4 gv = IO<DT_G>::load4(g, 4 * i) * grad_scale;
-        f32x4 mv = *reinterpret_cast<f32x4*>(m + 4 * i);
-        f32x4 vv = *reinterpret_cast<f32x4*>(v + 4 * i);
-        gv += pv * wd;
-        mv = mv * b1 + gv * (1.0f - b1);
-        vv = vv * b2 + (gv * gv) * (1.0f - b2);
-        f32x4 den_src = vv;
-        if (vmax) {
-            f32x4 vm = *reinterpret_cast<f32x4*>(vmax + 4 * i);
-            vm.x = fmaxf(vm.x, vv.x); vm.y = fmaxf(vm.y, vv.y); vm.z = fmaxf(vm.z, vv.z); vm.w = fmaxf(vm.w, vv.w);
-            *reinterpret_cast<f32x4*>(vmax + 4 * i) = vm;
-            den_src = vm;
-        }
-        f32x4 den;
-        den.x = sqrtf(den_src.x) / bc2_sqrt + eps; den.y = sqrtf(den_src.y) / bc2_sqrt + eps;
-        den.z = sqrtf(den_src.z) / bc2_sqrt + eps; den.w = sqrtf(den_src.w) / bc2_sqrt + eps;
-        const float step = lr / bc1;
-        pv.x -= step * (mv.x / den.x); pv.y -= step * (mv.y / den.y);
-        pv.z -= step * (mv.z / den.z); pv.w -= step * (mv.w / den.w);
-        *reinterpret_cast<f32x4*>(p + 4 * i) = pv;
-        *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
-        *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
-        if (shadow) IO<KVQ_BF16>::store4(shadow, 4 * i, pv);
+    const int64_t n8 = n4 >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = 8 * i;
+        f32x4 p0 = *reinterpret_cast<f32x4*>(p + e), p1 = *reinterpret_cast<f32x4*>(p + e + 4);
+        f32x4 m0 = *reinterpret_cast<f32x4*>(m + e), m1 = *reinterpret_cast<f32x4*>(m + e + 4);
+        f32x4 v0 = *reinterpret_cast<f32x4*>(v + e), v1 = *reinterpret_cast<f32x4*>(v + e + 4);
+        const f32x8 gv = IO<DT_G>::load8(g, e);
+        adam_update4(p0, gv.lo * grad_scale, m0, v0, vmax ? vmax + e : nullptr, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        adam_update4(p1, gv.hi * grad_scale, m1, v1, vmax ? vmax + e + 4 : nullptr, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        *reinterpret_cast<f32x4*>(p + e) = p0; *reinterpret_cast<f32x4*>(p + e + 4) = p1;
+        *reinterpret_cast<f32x4*>(m + e) = m0; *reinterpret_cast<f32x4*>(m + e + 4) = m1;
+        *reinterpret_cast<f32x4*>(v + e) = v0; *reinterpret_cast<f32x4*>(v + e + 4) = v1;
+        if (shadow) { f32x8 o = {p0, p1}; IO<KVQ_BF16>::store8(shadow, e, o); }
+    }
+    if ((n4 & 1) && blockIdx.x == 0 && threadIdx.x == 0) {                  // the odd 4-element chunk
+        const int64_t e = 4 * (n4 - 1);
+        f32x4 pv = *reinterpret_cast<f32x4*>(p + e), mv = *reinterpret_cast<f32x4*>(m + e), vv = *reinterpret_cast<f32x4*>(v + e);
+        adam_update4(pv, IO<DT_G>::load4(g, e) * grad_scale, mv, vv, vmax ? vmax + e : nullptr, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+        *reinterpret_cast<f32x4*>(p + e) = pv; *reinterpret_cast<f32x4*>(m + e) = mv; *reinterpret_cast<f32x4*>(v + e) = vv;
+        if (shadow) IO<KVQ_BF16>::store4(shadow, e, pv);
     }
 }
 
@@ -1889,7 +1906,8 @@ static int adam_launch(float* p, const void* g, float* m, float* v, float* vmax,
                        const float* hyper, void* stream) {
     KVQ_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0, "kvq_adam_step: bad argument (n %% 4 == 0)");
     const int64_t n4 = n / 4;
-    unsigned blocks = (unsigned)((n4 + 255) / 256 > 32768 ? 32768 : (n4 + 255) / 256);
+    const int64_t n8 = (n4 + 1) / 2;
+    unsigned blocks = (unsigned)((n8 + 255) / 256 > 32768 ? 32768 : (n8 + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DT(grad_dtype,
                 hipLaunchKernelGGL(adam_kernel<KVQ_F32>, dim3(blocks), dim3(256), 0, st, p, g, m, v, vmax, (unsigned short*)shadow_bf16, n4,
