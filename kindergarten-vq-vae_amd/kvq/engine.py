@@ -164,6 +164,7 @@ class _StepGraphs:
         torch.cuda.synchronize(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         step0 = eng._step_host
+        ok = False
         with torch.cuda.stream(side):
             eng._cap = self
             try:
@@ -173,11 +174,17 @@ class _StepGraphs:
                 self.out = eng.forward_backward(self.ids, self.mask, training=eng.model.training, compute_grads=True)
                 eng.optimizer_step()
                 self.graphs[-1].capture_end()
+                ok = True
             finally:
                 eng._cap = None
+                eng._step_host = step0      # capturing ran no captured kernel: the device step state did not move either
+                if not ok:                  # close the capture that was open when the error struck
+                    try:
+                        self.graphs[-1].capture_end()
+                    except Exception:
+                        pass
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        eng._step_host = step0              # capturing ran no captured kernel: the device step state did not move either
 
     def interlude(self, fn):
         """Called by the engine in the middle of the captured step: fn stays an eager launch between two graphs."""
@@ -849,8 +856,31 @@ class TrainEngine:
             if seen < 2 or len(self._graphs) >= 4:      # warm the workspaces / GEMM plans eagerly first; few shapes only
                 self._eager_seen[key] = seen + 1
                 return self._train_step_eager(input_ids, attention_mask)
-            g = self._graphs[key] = _StepGraphs(self, input_ids, attention_mask)
+            try:
+                g = self._graphs[key] = _StepGraphs(self, input_ids, attention_mask)
+            except Exception as e:                       # capture is an optimisation: never let it take a run down
+                import sys
+                print(f"[kvq] hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
+                      f"continuing with eager launches", file=sys.stderr, flush=True)
+                self._abandon_capture()
+                return self._train_step_eager(input_ids, attention_mask)
         return g.run(input_ids, attention_mask)
+
+    def _abandon_capture(self):
+        """Leave a failed capture behind in a state from which eager steps can go on (same collectives, same order)."""
+        self.use_graph, self._cap = False, None
+        self._graphs.clear()
+        try:
+            torch.cuda.synchronize(self.dev)
+        except Exception:
+            pass
+        if self.world > 1:
+            try:
+                self._wait_reductions()
+            except Exception:
+                self._works = []
+            self._pending_hi = self.flat.n
+        self._red_items, self._red_keep, self._wg_pending = [], [], False
 
     def eval_step(self, input_ids, attention_mask):
         return self.forward_backward(input_ids, attention_mask, training=False, compute_grads=False)

@@ -170,3 +170,27 @@ def test_engine_step_count_setter_moves_the_device_state():
     assert step == 42 and eng.step_count == 42
     np.testing.assert_allclose(lr, 1e-4, rtol=1e-6)
     np.testing.assert_allclose(bc1, 1 - 0.9 ** 42, rtol=2e-5)
+
+
+def test_engine_survives_a_failed_graph_capture(monkeypatch):
+    """Capture is an optimisation: an error inside it leaves the engine on the eager path with the same results."""
+    from kvq import engine as E
+    model = _build(torch.bfloat16).train()
+    eng = E.TrainEngine(model, lr=1e-3, seed=5)
+    ids, mask = _batch(B=8, S=16, seed=2)
+    calls = {"n": 0}
+    real = E.TrainEngine._emb_bwd
+
+    def flaky(self, *a, **k):
+        if self._cap is not None:
+            calls["n"] += 1
+            raise RuntimeError("injected failure during capture")
+        return real(self, *a, **k)
+    monkeypatch.setattr(E.TrainEngine, "_emb_bwd", flaky)
+    losses = [float(eng.train_step(ids, mask)["loss_recon"]) for _ in range(5)]
+    assert calls["n"] == 1 and eng.use_graph is False and not eng._graphs and eng.step_count == 5
+    monkeypatch.setattr(E.TrainEngine, "_emb_bwd", real)
+    ref = E.TrainEngine(_build(torch.bfloat16).train(), lr=1e-3, seed=5)
+    ref.use_graph = False
+    want = [float(ref.train_step(ids, mask)["loss_recon"]) for _ in range(5)]
+    np.testing.assert_allclose(losses, want, rtol=2e-2)
