@@ -61,7 +61,9 @@ def _load_gemm_tuning():
         tn.tuning_enable(os.environ.get("KVQ_GEMM_TUNING") == "tune")
         if os.environ.get("KVQ_GEMM_TUNING") == "tune":
             tn.set_filename(os.environ.get("KVQ_GEMM_TUNING_OUT", "gpurun_out/tunableop_new.csv"), False)
-            tn.set_max_tuning_duration(15)
+            tn.set_max_tuning_duration(int(os.environ.get("KVQ_GEMM_TUNING_MS", 15)))
+            if os.environ.get("KVQ_GEMM_TUNING_ITERS"):
+                tn.set_max_tuning_iterations(int(os.environ["KVQ_GEMM_TUNING_ITERS"]))
         else:
             tn.read_file(path)
             if hasattr(tn, "write_file_on_exit"):
