@@ -374,7 +374,7 @@ class TrainEngine:
     # split-K factors for the weight-gradient GEMMs gW[M,N] = gy[Ntok,M]^T x[Ntok,N]: the contraction (Ntok = 8192) is long
     # and the output small, so a single GEMM leaves most CUs idle; S batched slices + one sum fill the chip
     # (measured with tools/gemm_probe.py on MI355X, hipBLASLt 1.0: 1.3-1.8x over the plain call)
-    _SPLITS = {(768, 768): 16, (2304, 768): 8, (3072, 768): 4, (768, 3072): 4, (1536, 768): 8}
+    _SPLITS = {(768, 768): 4, (2304, 768): 8, (3072, 768): 4, (768, 3072): 4, (1536, 768): 8}     # tools/wgrad_split_probe.py
 
     # ------------------------------------------------------------------------------------------------------------
     # deferred small reductions: a layer's split-K slab sums and LayerNorm / bias partial sums go out as ONE launch
