@@ -314,6 +314,13 @@ int kvq_gumbel_forward(const void* logits, const float* noise, int64_t N, int K,
 int kvq_gumbel_backward(const void* logits, const float* y_soft, const void* g_y, const float* g_diff, int64_t N, int K, float tau,
                         float kld_scale, int io_dtype, void* g_logits, void* stream);
 
+
+/* Batched bf16 transposes, one launch: dst[i] [C][R] = src[i] [R][C]^T, i < n (device pointers in HOST arrays; not in place).
+ * Keeps W^T beside the 768x768 projection weights so that their input-gradient GEMM g.W runs as the NT product of
+ * kvq_gemm_nt_bf16 (refreshed once per optimiser step). */
+#define KVQ_TRANSPOSE_MAX 64
+int kvq_transpose_batch_bf16(const void* const* src, void* const* dst, int n, int R, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -344,6 +344,36 @@ __global__ __launch_bounds__(G_THREADS, 1) void gemm_nt_bf16_kernel3(GemmParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batched bf16 transposes: dst_i[C][R] = src_i[R][C]^T for up to KVQ_TRANSPOSE_MAX matrices of one shape in one launch.
+// The input-gradient GEMM g . W of a projection is an "NN" product; with W^T kept beside W (refreshed once per optimiser
+// step by this kernel, ~57 MB for the 48 768x768 weights of bert-base) it becomes the NT shape the kernel above is fast at.
+// 64x64 tiles through LDS, rows padded by one dword pair: conflict-free both ways.
+// ---------------------------------------------------------------------------------------------------------------
+struct TransposeBatch {
+    const unsigned short* src[KVQ_TRANSPOSE_MAX];
+    unsigned short* dst[KVQ_TRANSPOSE_MAX];
+    int R, C, n;
+};
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch tb) {
+    __shared__ unsigned short tile[64][66];
+    const unsigned short* src = tb.src[blockIdx.z];
+    unsigned short* dst = tb.dst[blockIdx.z];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < tb.R && c < tb.C) ? src[(size_t)r * tb.C + c] : (unsigned short)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < tb.C && r < tb.R) dst[(size_t)c * tb.R + r] = tile[tx][ty + 4 * i];
+    }
+}
+
 }  // namespace kvq
 
 using namespace kvq;
@@ -405,6 +435,22 @@ int kvq_gemm_nt_bf16_dgelu(const void* A, const void* B, const void* H, void* C,
                            void* stream) {
     KVQ_REQUIRE(H, "kvq_gemm_nt_bf16_dgelu: null pre-activation");
     return gemm_nt_launch(A, B, nullptr, C, M, N, K, lda, ldb, ldc, 0, EPI_DGELU, nullptr, H, stream);
+}
+
+int kvq_transpose_batch_bf16(const void* const* src, void* const* dst, int n, int R, int C, void* stream) {
+    KVQ_REQUIRE(src && dst && n >= 1 && R > 0 && C > 0, "kvq_transpose_batch_bf16: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int first = 0; first < n; first += KVQ_TRANSPOSE_MAX) {
+        TransposeBatch tb;
+        tb.R = R; tb.C = C; tb.n = n - first < KVQ_TRANSPOSE_MAX ? n - first : KVQ_TRANSPOSE_MAX;
+        for (int i = 0; i < tb.n; ++i) {
+            KVQ_REQUIRE(src[first + i] && dst[first + i] && src[first + i] != dst[first + i], "kvq_transpose_batch_bf16: matrix %d: null or in-place", first + i);
+            tb.src[i] = (const unsigned short*)src[first + i];
+            tb.dst[i] = (unsigned short*)dst[first + i];
+        }
+        hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64), (unsigned)tb.n), dim3(256), 0, st, tb);
+    }
+    return check_launch("transpose_batch_kernel");
 }
 
 }  // extern "C"

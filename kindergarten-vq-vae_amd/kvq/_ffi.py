@@ -69,6 +69,7 @@ SIGNATURES = {
                             C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
     "kvq_gemm_nt_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_set_stages": (_int, [_int]),
+    "kvq_transpose_batch_bf16": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int, _int, _int, _vp]),
     "kvq_gemm_nt_bf16_gelu": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_nt_bf16_dgelu": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_attn_set_variant": (_int, [_int]),

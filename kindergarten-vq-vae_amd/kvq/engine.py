@@ -243,6 +243,7 @@ class TrainEngine:
         self._step_host = 0
         self._step_seed = (self.seed * 1000003) & 0x7FFFFFFFFFFFFFF      # + step count on the device
         self._graphs, self._eager_seen, self._cap = {}, {}, None
+        self._own_fwd = os.environ.get("KVQ_OWN_GEMM", "1") != "0"
         # opt-in (KVQ_WG_STREAM=1): weight-gradient GEMMs on a side stream.  Measured on MI355X with the step replayed from
         # hipGraphs: 23.6 ms/step against 22.5 ms on one stream -- two concurrent hipBLASLt kernels share CUs and L2 badly
         self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get("KVQ_WG_STREAM", "0") == "1" else None
@@ -336,6 +337,17 @@ class TrainEngine:
         self._works = []
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         _load_gemm_tuning()
+        # W^T beside every square projection weight of the _OWN_GEMM shapes (bf16 only): their input-gradient GEMM then runs
+        # as an NT product on csrc/kvq_gemm.hip; one batched transpose per optimiser step keeps the copies current
+        self._wT, self._wT_op = {}, None
+        if self.dtype == torch.bfloat16 and os.environ.get("KVQ_OWN_DGRAD", "0") == "1":
+            names = [n for n, (_o, _n, shape) in self.flat.seg.items()
+                     if len(shape) == 2 and tuple(shape) in self._OWN_GEMM and shape[0] == shape[1] and n.endswith(".w")
+                     and ".sa.q." not in n and ".sa.k." not in n and ".sa.v." not in n and ".ca.k." not in n and ".ca.v." not in n]
+            if names:
+                self._wT = {n: torch.empty(tuple(self.flat.seg[n][2]), dtype=torch.bfloat16, device=dev) for n in names}
+                self._wT_op = nnops.TransposeBatch([self.flat.w(n) for n in names], [self._wT[n] for n in names])
+                self._wT_op.run()
 
     # ------------------------------------------------------------------------------------------------------------
     # small helpers
@@ -367,7 +379,7 @@ class TrainEngine:
     def _linear(self, x, wname, bname, fused=None):
         W = self.flat.fused(fused[0], self.flat.shadow) if fused else self.flat.w(wname)
         b = self.flat.fused(fused[1], self.flat.shadow) if fused else self.flat.w(bname)
-        if self.dtype == torch.bfloat16 and tuple(W.shape) in self._OWN_GEMM and x.shape[0] >= 2048 and x.is_contiguous():
+        if self._own_fwd and self.dtype == torch.bfloat16 and tuple(W.shape) in self._OWN_GEMM and x.shape[0] >= 2048 and x.is_contiguous():
             return nnops.gemm_nt(x, W, b)
         return torch.addmm(b, x, W.t())
 
@@ -448,6 +460,13 @@ class TrainEngine:
             self._wgrad(gy, x, gW)
         if fl.trainable[bnames[0]] and not bias_done:     # bias_done: the LayerNorm backward kernel already produced it
             self._defer_colsum(gy, gb)
+        WT = self._wT.get(wnames[0]) if len(wnames) == 1 else None
+        if WT is not None and gy.shape[0] >= 2048 and gy.is_contiguous() and (need_gx or gx_accum is not None):
+            # g . W as the NT product g . (W^T)^T on the transposed shadow copy: the shape where kvq_gemm.hip beats the library
+            if gx_accum is not None and not gx_accum.is_contiguous():
+                WT = None
+            else:
+                return nnops.gemm_nt(gy, WT, None, out=gx_accum, accumulate=gx_accum is not None)
         if gx_accum is not None:
             gx_accum.addmm_(gy, W)
             return gx_accum
@@ -826,11 +845,15 @@ class TrainEngine:
         if self.has_vq and self.E.requires_grad:
             nnops.adam_step_dev(self.E.data.view(-1), self.gE.view(-1), self.mE.view(-1), self.vE.view(-1), self._state,
                                 b1, b2, self.eps, self.wd, vmax=self.vmaxE.view(-1) if self.vmaxE is not None else None)
+        if self._wT_op is not None:
+            self._wT_op.run()
 
     def sync_from_model(self):
         """Call after the model's parameters were written from outside (load_state_dict, manual init): refreshes the bf16
         shadow weights the GEMMs read.  (The f32 master buffer IS the parameters' storage, nothing to copy there.)"""
         self.flat.refresh_shadow()
+        if self._wT_op is not None:
+            self._wT_op.run()
 
     @staticmethod
     def supports(model, seq_len: int) -> bool:

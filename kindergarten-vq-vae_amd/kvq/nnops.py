@@ -219,6 +219,26 @@ def embed_grad(g, perm, sorted_ids, gW, accumulate=False):
     return gW
 
 
+class TransposeBatch:
+    """dst[i] = src[i].T for lists of same-shaped contiguous bf16 matrices, one launch (pointer tables built once)."""
+
+    def __init__(self, srcs, dsts):
+        import ctypes
+        assert len(srcs) == len(dsts) and len(srcs) >= 1
+        self.R, self.C = srcs[0].shape
+        for a, b in zip(srcs, dsts):
+            require_gpu(a, b)
+            assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.is_contiguous() and b.is_contiguous()
+            assert tuple(a.shape) == (self.R, self.C) and tuple(b.shape) == (self.C, self.R)
+        self.n = len(srcs)
+        self._keep = (list(srcs), list(dsts))
+        self._src = (ctypes.c_void_p * self.n)(*[a.data_ptr() for a in srcs])
+        self._dst = (ctypes.c_void_p * self.n)(*[b.data_ptr() for b in dsts])
+
+    def run(self):
+        check(lib().kvq_transpose_batch_bf16(self._src, self._dst, self.n, self.R, self.C, stream_ptr()), "kvq_transpose_batch_bf16")
+
+
 def gemm_nt(a, b, bias=None, out=None, accumulate=False):
     """out[M,N] (= | +=) a[M,K] @ b[N,K].T (+ bias), bf16, hand-written MFMA kernel (csrc/kvq_gemm.hip)."""
     require_gpu(a, b)

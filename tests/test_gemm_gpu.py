@@ -66,3 +66,16 @@ def test_gemm_rejects_unsupported_shapes(ops):
     w = torch.randn(64, 100, device="cuda").bfloat16()
     with pytest.raises(KvqError):
         ops.gemm_nt(a, w)                                    # K % 64 != 0
+
+
+def test_transpose_batch():
+    from kvq import nnops
+    torch.manual_seed(0)
+    srcs = [torch.randn(768, 768, device="cuda").bfloat16() for _ in range(70)]          # > KVQ_TRANSPOSE_MAX: two launches
+    dsts = [torch.empty(768, 768, device="cuda", dtype=torch.bfloat16) for _ in srcs]
+    op = nnops.TransposeBatch(srcs, dsts)
+    op.run()
+    assert all(torch.equal(d, s.t()) for s, d in zip(srcs, dsts))
+    a = torch.randn(100, 36, device="cuda").bfloat16(); b = torch.empty(36, 100, device="cuda", dtype=torch.bfloat16)
+    nnops.TransposeBatch([a], [b]).run()
+    assert torch.equal(b, a.t())
