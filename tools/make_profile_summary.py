@@ -15,7 +15,7 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = [f"# {tag} profile summaries (1x MI355X, rocprofv3, ROCm 7.2)", "",
        "## Training step: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 10 --warmup 3`",
        f"{steps} steps traced (3 warm-up + 10 timed); total kernel time {tot/1e6:.1f} ms = {tot/1e6/steps:.2f} ms/step "
-       f"(profiled runs are ~10 % slower than un-profiled ones). Full CSV: `profiles/{tag}_step_kernel_stats.csv`.", "",
+       f"(sum of kernel durations under the profiler; the un-profiled wall-clock step of the same recipe is in `profiles/{tag}_bench_line.json`). Full CSV: `profiles/{tag}_step_kernel_stats.csv`.", "",
        "| kernel | calls | ms/step | avg us | % |", "|---|---|---|---|---|"]
 for r in rows[:30]:
     out.append(f"| `{r['Name'][:72]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6/steps:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
