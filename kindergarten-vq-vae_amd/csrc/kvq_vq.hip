@@ -747,7 +747,7 @@ __global__ __launch_bounds__(GEN_WAVES* WAVE) void vq_fwd_generic_kernel(FwdPara
 // finalize: loss and perplexity from the per-token / per-code partials, fixed reduction order
 //   VectorQuantizer.py:76-77 and :84-85
 // -------------------------------------------------------------------------------------------------------------
-constexpr int FIN_THREADS = 256;
+constexpr int FIN_THREADS = 1024;   // one workgroup: the per-token partials are a 64 KB latency-bound read
 
 __global__ __launch_bounds__(FIN_THREADS) void vq_finalize_kernel(const double* __restrict__ tok_sumsq,
                                                                    const unsigned* __restrict__ counts_u,
