@@ -334,7 +334,8 @@ class TrainEngine:
         self._avg_in_comm = self.world > 1 and dist.get_backend(process_group) == "nccl"   # RCCL averages itself; gloo sums
         self.chunk = max(bucket_mib * (1 << 20) // self.flat.grad.element_size(), 1 << 16)     # elements per all-reduce chunk
         self._pending_hi = self.flat.n
-        self._works = []
+        self._works, self._works_late = [], []
+        self._ev_early = torch.cuda.Event() if self.world > 1 else None
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         _load_gemm_tuning()
         # W^T beside every square projection weight of the _OWN_GEMM shapes (bf16 only): their input-gradient GEMM then runs
@@ -621,8 +622,9 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------------------------
     # gradient exchange (multi-GPU): all-reduce finished tail chunks of the flat gradient buffer while backward runs
     # ------------------------------------------------------------------------------------------------------------
-    def _grads_done_down_to(self, name):
-        """Every gradient located at or after segment `name` is final (once the queued reductions have been launched)."""
+    def _grads_done_down_to(self, name, partial=False):
+        """Every gradient located at or after segment `name` is final (once the queued reductions have been launched).
+        `partial`: also send the incomplete chunk above `name` (used before the last, late part of backward)."""
         self._flush_reductions()
         if self.world == 1:
             return
@@ -630,14 +632,18 @@ class TrainEngine:
         while self._pending_hi - self.chunk >= lo:
             self._reduce(self._pending_hi - self.chunk, self._pending_hi)
             self._pending_hi -= self.chunk
+        if partial and self._pending_hi > lo:
+            self._reduce(lo, self._pending_hi)
+            self._pending_hi = lo
 
-    def _all_reduce_avg(self, t):
+    def _all_reduce_avg(self, t, late=False):
+        works = self._works_late if late else self._works
         self.comm_stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.comm_stream):
             if self._avg_in_comm:
-                self._works.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+                works.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
             else:
-                self._works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
+                works.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
 
     def _eager(self, fn):
         """Run fn now; while a step is being captured it also becomes an eager launch between two graphs of the replay."""
@@ -650,24 +656,30 @@ class TrainEngine:
         t = self.flat.grad[a:b]
         self._eager(lambda: self._all_reduce_avg(t))
 
-    def _wait_reductions(self):
+    def _settle(self, works):
+        """On the side stream: wait for these collectives (and finish the average where the backend only sums)."""
         with torch.cuda.stream(self.comm_stream):     # work.wait() orders the CURRENT stream behind the collective's result:
-            for w, t in self._works:                  # the side stream must be the one that waits before it divides
+            for w, t in works:                        # the side stream must be the one that waits before it divides
                 w.wait()
                 if t is not None:
                     t.div_(self.world)
-        self._works = []
-        torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
+        works.clear()
 
-    def _grads_finish(self):
-        if self.world == 1:
-            return
-        if self._pending_hi > 0:
-            self._reduce(0, self._pending_hi)
+    def _exchange_head(self, cut):
+        """End of backward.  Everything above `cut` was sent while backward ran: settle it and let the optimiser start on
+        that part; the head of the buffer [0, cut) -- the embedding gradients, final only now -- and the codebook gradient
+        go out behind it and are waited for by _exchange_tail(), i.e. their all-reduce overlaps with Adam on the rest."""
+        self._settle(self._works)
+        self._ev_early.record(self.comm_stream)
+        if cut > 0:
+            self._all_reduce_avg(self.flat.grad[:cut], late=True)
         if self.has_vq:
-            self._eager(lambda: self._all_reduce_avg(self.gE))
-        self._eager(self._wait_reductions)
-        self._pending_hi = self.flat.n
+            self._all_reduce_avg(self.gE, late=True)
+        torch.cuda.current_stream(self.dev).wait_event(self._ev_early)
+
+    def _exchange_tail(self):
+        self._settle(self._works_late)
+        torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
 
     # ------------------------------------------------------------------------------------------------------------
     # one training step
@@ -818,7 +830,7 @@ class TrainEngine:
                 sa, ff = enc_saved[i]
                 g_x = self._ffn_bwd(f"enc.{i}.", g_x, ff)
                 g_x = self._attn_block_bwd(f"enc.{i}.sa.", g_x, sa)
-                self._grads_done_down_to(f"enc.{i}.sa.q.w")
+                self._grads_done_down_to(f"enc.{i}.sa.q.w", partial=(i == 0))
                 enc_saved[i] = None
             self._emb_bwd("enc.emb.", g_x, emb_saved)
         self._flush_reductions()
@@ -831,17 +843,31 @@ class TrainEngine:
                                    z_q.data_ptr(), idx.data_ptr(), vq_out[0:].data_ptr(), vq_out[1:].data_ptr(), None,
                                    ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward")
 
-    def optimizer_step(self):
-        self._grads_finish()
-        self._step_host += 1
+    def _adam_ranges(self, lo, hi):
         fl = self.flat
         b1, b2 = self.betas
+        for (a, b) in fl.ranges:
+            a, b = max(a, lo), min(b, hi)
+            if a < b:
+                nnops.adam_step_dev(fl.master[a:b], fl.grad[a:b], fl.m[a:b], fl.v[a:b], self._state, b1, b2, self.eps, self.wd,
+                                    vmax=fl.vmax[a:b] if fl.vmax is not None else None,
+                                    shadow=fl.shadow[a:b] if fl.shadow is not fl.master else None)
+
+    def optimizer_step(self):
+        fl = self.flat
+        b1, b2 = self.betas
+        cut = 0
+        if self.world > 1:
+            cut = self._pending_hi                    # [0, cut) has not been sent yet (embedding gradients)
+            self._eager(lambda: self._exchange_head(cut))
+            self._pending_hi = fl.n
+        self._step_host += 1
         # step += 1, lr after the milestones, bias corrections: computed on the device, read there by the Adam kernels
         nnops.step_state_advance(self._state, self.lr, self.gamma, self.milestones, b1, b2)
-        for (a, b) in fl.ranges:
-            nnops.adam_step_dev(fl.master[a:b], fl.grad[a:b], fl.m[a:b], fl.v[a:b], self._state, b1, b2, self.eps, self.wd,
-                                vmax=fl.vmax[a:b] if fl.vmax is not None else None,
-                                shadow=fl.shadow[a:b] if fl.shadow is not fl.master else None)
+        self._adam_ranges(cut, fl.n)                  # multi-GPU: runs while the head of the buffer is still being reduced
+        if self.world > 1:
+            self._eager(self._exchange_tail)
+            self._adam_ranges(0, cut)
         if self.has_vq and self.E.requires_grad:
             nnops.adam_step_dev(self.E.data.view(-1), self.gE.view(-1), self.mE.view(-1), self.vE.view(-1), self._state,
                                 b1, b2, self.eps, self.wd, vmax=self.vmaxE.view(-1) if self.vmaxE is not None else None)
@@ -901,9 +927,10 @@ class TrainEngine:
             pass
         if self.world > 1:
             try:
-                self._wait_reductions()
+                self._settle(self._works)
+                self._exchange_tail()
             except Exception:
-                self._works = []
+                self._works, self._works_late = [], []
             self._pending_hi = self.flat.n
         self._red_items, self._red_keep, self._wg_pending = [], [], False
 
