@@ -194,3 +194,27 @@ def test_engine_survives_a_failed_graph_capture(monkeypatch):
     ref.use_graph = False
     want = [float(ref.train_step(ids, mask)["loss_recon"]) for _ in range(5)]
     np.testing.assert_allclose(losses, want, rtol=2e-2)
+
+
+def test_engine_graphs_per_shape_interleaved_with_eval():
+    """Two batch shapes (two captured step chains), evaluation steps in between, a return to the first shape: same trajectory
+    as the engine that launches every kernel eagerly."""
+    from kvq.engine import TrainEngine
+    a, b = _batch(B=8, S=16, seed=11), _batch(B=4, S=32, seed=12)
+    plan = [("t", a)] * 3 + [("e", b)] + [("t", b)] * 3 + [("e", a)] + [("t", a)] * 2 + [("t", b)]
+    runs = []
+    for use_graph in (False, True):
+        model = _build(torch.bfloat16)
+        eng = TrainEngine(model, lr=1e-3, seed=3)
+        eng.use_graph = use_graph
+        out = []
+        for kind, (ids, mask) in plan:
+            if kind == "t":
+                model.train()
+                out.append(float(eng.train_step(ids, mask)["loss_recon"]))
+            else:
+                model.eval()
+                out.append(float(eng.eval_step(ids, mask)["loss_recon"]))
+        assert len(eng._graphs) == (2 if use_graph else 0) and eng.step_count == 9
+        runs.append(out)
+    np.testing.assert_allclose(runs[0], runs[1], rtol=2e-2, atol=2e-3)
