@@ -58,6 +58,25 @@ __device__ __forceinline__ void ms_push(MaxSum& a, float x, int i) {
     else a.s += __expf(x - a.m);
     if (x > a.bv || (x == a.bv && i < a.bi)) { a.bv = x; a.bi = i; }
 }
+// a whole 16-byte vector at once: one rescale at most, VEC exponentials, the arg-max only looked at when the vector's
+// maximum beats the running one (indices grow along a thread's walk, so an equal value never replaces an earlier one)
+template <int VEC>
+__device__ __forceinline__ void ms_push_vec(MaxSum& a, const float (&v)[VEC], int i0) {
+    float vm = v[0];
+#pragma unroll
+    for (int u = 1; u < VEC; ++u) vm = fmaxf(vm, v[u]);
+    if (vm > a.m) { a.s *= __expf(a.m - vm); a.m = vm; }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) s += __expf(v[u] - a.m);
+    a.s += s;
+    if (vm > a.bv) {
+        int iu = VEC - 1;
+#pragma unroll
+        for (int u = VEC - 2; u >= 0; --u) iu = v[u] == vm ? u : iu;
+        a.bv = vm; a.bi = i0 + iu;
+    }
+}
 __device__ __forceinline__ void ms_merge(MaxSum& a, float m, float s, float bv, int bi) {
     const float M = fmaxf(a.m, m);
     const float sa = (a.m == -INFINITY) ? 0.f : a.s * __expf(a.m - M);
@@ -81,8 +100,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const void* __restri
     for (int q = t; q < rw.nvec; q += CE_THREADS) {
         float v[VEC];
         load_vec<DT>(rw.base + ((size_t)rw.head + (size_t)q * VEC) * IO<DT>::bytes, v);
-#pragma unroll
-        for (int u = 0; u < VEC; ++u) ms_push(a, v[u], rw.head + q * VEC + u);
+        ms_push_vec<VEC>(a, v, rw.head + q * VEC);
     }
     for (int j = rw.tail0 + t; j < V; j += CE_THREADS) ms_push(a, IO<DT>::load1(rw.base, j), j);
 #pragma unroll
