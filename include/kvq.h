@@ -147,6 +147,12 @@ int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, 
 /* g_logits[n,v] = g_loss/N * (softmax(logits_n)[v] - [v == target_n]); may alias logits (in place). */
 int kvq_ce_backward(const void* logits, const int64_t* target, const float* row_lse, const float* g_loss,
                     int64_t N, int V, int64_t ld, int io_dtype, void* g_logits, void* stream);
+/* kvq_ce_backward that also leaves bias_part [kvq_ce_bwd_partial_rows(N)][ld] f32 = partial column sums of g_logits (as stored):
+ * the gradient of the LM-head output bias (modeling_bert.py:483-497), finished by kvq_reduce_batch -- no second pass over
+ * the [N, V] gradient.  Needs ld %% 8 == 0 and 16-byte aligned buffers; columns V .. ld of g_logits and of the sums are 0. */
+int64_t kvq_ce_bwd_partial_rows(int64_t N);
+int kvq_ce_backward_bias(const void* logits, const int64_t* target, const float* row_lse, const float* g_loss, int64_t N,
+                         int V, int64_t ld, int io_dtype, void* g_logits, float* bias_part, size_t part_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Memory-bound pieces of the BERT blocks (HuggingFace modeling_bert.py as used by models/bagon/Bagon.py:24-31),

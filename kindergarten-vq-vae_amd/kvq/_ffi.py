@@ -46,6 +46,8 @@ SIGNATURES = {
     "kvq_gumbel_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, _int, _vp, _vp]),
     "kvq_ce_forward": (_int, [_vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kvq_ce_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp]),
+    "kvq_ce_bwd_partial_rows": (_i64, [_i64]),
+    "kvq_ce_backward_bias": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _sz, _vp]),
     "kvq_dropout_residual_ln_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp]),
     "kvq_ln_bwd_workspace_bytes": (_sz, [_i64, _int]),
     "kvq_dropout_residual_ln_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp,

@@ -764,11 +764,20 @@ class TrainEngine:
         # ---------------- backward ----------------
         tr = fl.trainable
         g_scale = self._ones * self.w_recon
-        check(lib().kvq_ce_backward(logits.data_ptr(), tgt.data_ptr(), row_lse.data_ptr(), g_scale.data_ptr(), N, self.V, self.Vp,
-                                    self.io, logits.data_ptr(), stream_ptr()), "kvq_ce_backward")      # in place: logits := d loss / d logits
-        g_logits = logits
-        if tr["head.bias"]:
-            self._defer_colsum(g_logits, fl.g("head.bias", rows=self.Vp))
+        if tr["head.bias"] and self.Vp % 8 == 0:
+            # in place: logits := d loss / d logits; the LM-head bias gradient leaves the same pass as partial column sums
+            pb = torch.empty((lib().kvq_ce_bwd_partial_rows(N), self.Vp), dtype=torch.float32, device=self.dev)
+            check(lib().kvq_ce_backward_bias(logits.data_ptr(), tgt.data_ptr(), row_lse.data_ptr(), g_scale.data_ptr(), N, self.V,
+                                             self.Vp, self.io, logits.data_ptr(), pb.data_ptr(), pb.numel() * 4, stream_ptr()),
+                  "kvq_ce_backward_bias")
+            self._defer(pb, fl.g("head.bias", rows=self.Vp), pb.shape[0], self.Vp, self.Vp)
+            g_logits = logits
+        else:
+            check(lib().kvq_ce_backward(logits.data_ptr(), tgt.data_ptr(), row_lse.data_ptr(), g_scale.data_ptr(), N, self.V, self.Vp,
+                                        self.io, logits.data_ptr(), stream_ptr()), "kvq_ce_backward")      # in place
+            g_logits = logits
+            if tr["head.bias"]:
+                self._defer_colsum(g_logits, fl.g("head.bias", rows=self.Vp))
         if tr["dec.emb.word"]:
             self._wgrad(g_logits, hN, fl.g("dec.emb.word", rows=self.Vp))            # [Vp,H] = g_logits^T hN
         g_hN = torch.mm(g_logits, Wv)

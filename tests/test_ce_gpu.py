@@ -71,3 +71,30 @@ def test_ce_inplace_backward(kvq):
     lb.backward()
     assert torch.equal(lin.bias.grad, a.grad.float().sum(0).bfloat16()) or \
         torch.allclose(lin.bias.grad.float(), a.grad.float().sum(0), rtol=2e-2, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,V,ld", [(100, 1000, 1000), (77, 30522, 30528), (33, 13, 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ce_backward_with_bias_partials_equals_plain_backward(kvq, N, V, ld, dtype):
+    """The row-block-tiled backward (kvq_ce_backward_bias): same gradient as the per-row kernel, zero padding columns, and
+    partial rows that sum to the column sums of the stored gradient (the LM-head bias gradient)."""
+    from kvq._ffi import check, lib, stream_ptr
+    torch.manual_seed(N + V)
+    io = 0 if dtype == torch.float32 else 1
+    logits = (3 * torch.randn(N, ld, device="cuda")).to(dtype)
+    tgt = torch.randint(0, V, (N,), device="cuda")
+    rl = torch.empty(N, device="cuda"); lse = torch.empty(N, device="cuda"); pred = torch.empty(N, dtype=torch.int64, device="cuda")
+    check(lib().kvq_ce_forward(logits.data_ptr(), tgt.data_ptr(), N, V, ld, io, rl.data_ptr(), lse.data_ptr(), pred.data_ptr(), None, None, stream_ptr()), "fwd")
+    gs = torch.full((1,), 1.3, device="cuda")
+    g0 = torch.empty_like(logits)
+    check(lib().kvq_ce_backward(logits.data_ptr(), tgt.data_ptr(), lse.data_ptr(), gs.data_ptr(), N, V, ld, io, g0.data_ptr(), stream_ptr()), "bwd")
+    P = lib().kvq_ce_bwd_partial_rows(N)
+    part = torch.full((P, ld), 7.0, device="cuda")
+    g1 = logits.clone()                                              # in place, as the engine runs it
+    check(lib().kvq_ce_backward_bias(g1.data_ptr(), tgt.data_ptr(), lse.data_ptr(), gs.data_ptr(), N, V, ld, io, g1.data_ptr(),
+                                     part.data_ptr(), part.numel() * 4, stream_ptr()), "bwd_bias")
+    torch.testing.assert_close(g1.float(), g0.float(), rtol=1e-5, atol=1e-9)
+    assert torch.all(g1[:, V:] == 0) and torch.all(part[:, V:] == 0)
+    torch.testing.assert_close(part.sum(0), g1.float().sum(0), rtol=1e-4, atol=1e-6)
+    assert lib().kvq_ce_backward_bias(g1.data_ptr(), tgt.data_ptr(), lse.data_ptr(), gs.data_ptr(), N, V, ld, io, g1.data_ptr(),
+                                      part.data_ptr(), 16, stream_ptr()) != 0          # partial buffer too small
