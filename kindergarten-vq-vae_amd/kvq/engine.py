@@ -497,7 +497,7 @@ class TrainEngine:
         if keep is not None:
             g = nnops.dropout(g, keep[0], self._step_seed, keep[1])
         tr = fl.trainable
-        g_y, g_pt = nnops.ln_bwd(g, pre, mean, rstd, fl.w32(prefix + "ln.w"),
+        g_y, g_pt = self._ln_bwd(g, pre, mean, rstd, fl.w32(prefix + "ln.w"), 0.0, 0, 0,
                                  g_gamma=fl.g(prefix + "ln.w") if tr[prefix + "ln.w"] else None,
                                  g_beta=fl.g(prefix + "ln.b") if tr[prefix + "ln.b"] else None)
         if tr[prefix + "word"]:
@@ -517,14 +517,19 @@ class TrainEngine:
                     gw.add_(acc.to(gw.dtype))          # LM-head weight gradient is already in there
                 else:
                     gw.copy_(acc)
+        # position rows get the sum over sentences, token-type row 0 the sum over all tokens: two column sums of g_pt seen as
+        # [B, S*H] and [N, H], finished by the layer's batched reduction (rows that are not looked up keep a zero gradient)
+        Hh = g_pt.shape[1]
         if tr[prefix + "pos"]:
             gp = fl.g(prefix + "pos")
             gp.zero_()
-            gp[:S] = g_pt.view(B, S, -1).float().sum(0).to(gp.dtype)
+            part = nnops.colsum_partial(g_pt.view(B, S * Hh))
+            self._defer(part, gp[:S], part.shape[0], S * Hh, S * Hh)
         if tr[prefix + "type"]:
             gt = fl.g(prefix + "type")
             gt.zero_()
-            gt[0] = g_pt.float().sum(0).to(gt.dtype)
+            part = nnops.colsum_partial(g_pt)
+            self._defer(part, gt[0], part.shape[0], Hh, Hh)
 
     def _attn_block_fwd(self, pre, x, kv_src, mask, causal, cfg, training, B, Sq, Sk, kv_pre=None):
         """self-attention (kv_src is None) or cross-attention on kv_src (kv_pre: its already projected [N, 2H] keys | values,
