@@ -376,3 +376,21 @@ def test_embed_grad_matches_index_add(ops, H, gdt, wdt, pattern):
     gw3 = torch.zeros(V, H, device="cuda", dtype=wdt)
     ops.embed_grad(g, perm, sid, gw3)
     assert torch.equal(gw3, gw)                                       # deterministic
+
+
+def test_embed_grad_full_size_properties(ops):
+    """BASELINE configs[1] size (N = 8192 tokens, V = 30522, H = 768, ~60 % pad tokens): linearity (the rows of gW add up to the
+    column sums of g), untouched rows stay zero, and equality with an f64 scatter-add."""
+    torch.manual_seed(0)
+    N, V, H = 8192, 30522, 768
+    ids = torch.randint(1000, 30000, (N,), device="cuda")
+    ids[torch.rand(N, device="cuda") < 0.6] = 0
+    g = torch.randn(N, H, device="cuda").bfloat16()
+    sid, perm = torch.sort(ids, stable=True)
+    gw = torch.zeros(V, H, device="cuda", dtype=torch.float32)
+    ops.embed_grad(g, perm, sid, gw)
+    torch.testing.assert_close(gw.sum(0), g.float().sum(0), rtol=1e-4, atol=2e-3)
+    used = torch.zeros(V, dtype=torch.bool, device="cuda"); used[ids] = True
+    assert torch.all(gw[~used] == 0)
+    ref = torch.zeros(V, H, device="cuda", dtype=torch.float64).index_add_(0, ids, g.double())
+    torch.testing.assert_close(gw.double(), ref, rtol=1e-5, atol=1e-4)
