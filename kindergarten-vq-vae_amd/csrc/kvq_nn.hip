@@ -1027,10 +1027,24 @@ __device__ __forceinline__ int attn_key(int h, int jj) { return LAY ? 8 * (jj >>
 
 // dropout keep-scales of the lane's 16 prob elements (b, head, i, j): element index ((bh*32 + i)*32 + j), 4 per Philox call
 // (both layouts own keys in aligned groups of four, so every flavour of the kernels draws the same mask)
+// key-padding mask of sentence b as one wave-wide bit mask (lane l < 32 loads mask[b][min(l, Sk-1)] unconditionally, ballot
+// collects) and the effective dropout seed: two dependent global loads the MFMA kernels issue at their very top, long before
+// the scores exist
+__device__ __forceinline__ unsigned long long attn_key_mask(const AttnParams& p, int b) {
+    unsigned long long kmask = ~0ull;
+    if (p.mask) {                                                   // wave-uniform branch
+        const int l = threadIdx.x & 31;
+        const int64_t mv = p.mask[(size_t)b * p.Sk + (l < p.Sk ? l : p.Sk - 1)];
+        kmask = __ballot(mv != 0);
+    }
+    return kmask;
+}
+__device__ __forceinline__ unsigned long long attn_seed(const AttnParams& p) { return p.seed + (p.seed_off ? *p.seed_off : 0ull); }
+
 template <int LAY = 0>
-__device__ __forceinline__ void attn_keep16(const AttnParams& p, int bh, int i, int h, float (&keep)[16]) {
+__device__ __forceinline__ void attn_keep16(const AttnParams& p, int bh, int i, int h, float (&keep)[16], const unsigned long long* seed_pre = nullptr) {
     const float inv_keep = 1.0f / (1.0f - p.p_drop);
-    const unsigned long long seed = p.seed + (p.seed_off ? *p.seed_off : 0ull);
+    const unsigned long long seed = seed_pre ? *seed_pre : attn_seed(p);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const unsigned long long e4 = (((unsigned long long)bh * AT_S + i) * AT_S + attn_key<LAY>(h, 4 * c)) >> 2;
@@ -1076,14 +1090,9 @@ __device__ __forceinline__ void weighted_rows32(const float* C, int cs, const T*
 
 // scaled + masked scores -> probabilities (before dropout) of query i against the lane's 16 keys, and the row's lse
 template <int LAY = 0>
-__device__ __forceinline__ void scores_to_probs(const AttnParams& p, int b, int i, int h, bool qvalid, float (&s)[16], float& lse_out) {
-    // key-padding mask as one wave-wide bit mask: lane l < 32 loads mask[b][min(l, Sk-1)] unconditionally, ballot collects
-    unsigned long long kmask = ~0ull;
-    if (p.mask) {                                                   // wave-uniform branch
-        const int l = threadIdx.x & 31;
-        const int64_t mv = p.mask[(size_t)b * p.Sk + (l < p.Sk ? l : p.Sk - 1)];
-        kmask = __ballot(mv != 0);
-    }
+__device__ __forceinline__ void scores_to_probs(const AttnParams& p, int b, int i, int h, bool qvalid, float (&s)[16], float& lse_out,
+                                                const unsigned long long* kmask_pre = nullptr) {
+    const unsigned long long kmask = kmask_pre ? *kmask_pre : attn_key_mask(p, b);
     float mx = -INFINITY;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
@@ -1571,6 +1580,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
     load_row_chunks(p.k, ((size_t)b * p.Sk + rk) * p.ldk + hd * AT_D, h, kvalid, kf);
     load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
     load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
+    const unsigned long long kmask = attn_key_mask(p, b), seed = attn_seed(p);       // in flight with the row loads
     f32x16 acc = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma32(kf[s], qf[s], acc);      // S^T[key][query]
@@ -1579,10 +1589,10 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) s[v] = acc[v];
     float lse;
-    scores_to_probs<1>(p, b, r, h, qvalid, s, lse);
+    scores_to_probs<1>(p, b, r, h, qvalid, s, lse, &kmask);
     if (p.p_drop > 0.f) {
         float keep[16];
-        attn_keep16<1>(p, bh, r, h, keep);
+        attn_keep16<1>(p, bh, r, h, keep, &seed);
 #pragma unroll
         for (int v = 0; v < 16; ++v) s[v] *= keep[v];
     }
@@ -1612,6 +1622,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
     load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
     load_row_chunks(p.g_out, ((size_t)b * p.Sq + rq) * p.ldo + hd * AT_D, h, qvalid, gf);
+    const unsigned long long kmask = attn_key_mask(p, b), seed = attn_seed(p);       // in flight with the row loads
     f32x16 accS = zero16(), accP = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) accS = mfma32(kf[s], qf[s], accS);     // S^T[key][query]
@@ -1624,9 +1635,9 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) { s[v] = accS[v]; dp[v] = accP[v]; }
     float lse;
-    scores_to_probs<1>(p, b, r, h, qvalid, s, lse);
+    scores_to_probs<1>(p, b, r, h, qvalid, s, lse, &kmask);
     float keep[16];
-    if (p.p_drop > 0.f) attn_keep16<1>(p, bh, r, h, keep);
+    if (p.p_drop > 0.f) attn_keep16<1>(p, bh, r, h, keep, &seed);
     else {
 #pragma unroll
         for (int v = 0; v < 16; ++v) keep[v] = 1.0f;
