@@ -95,7 +95,25 @@ def end_of_step_stats_update(stats_stage_run: dict, stats_step: dict, n_els_batc
 _LOWER_IS_BETTER = {"loss_recon": True, "loss_vq": True, "metric_perp": False, "loss_full": True, "metric_acc": False}
 
 
+def _sum_over_ranks(stats_stage_run: dict, n_els_epoch: int):
+    """Data-parallel runs: every rank has accumulated the sums of ITS shard; one small all-reduce per stage and epoch turns
+    them into sums over the whole split, so the printed / logged means and the best-checkpoint decision are the ones a single
+    process on the global batch would make (the reference is single-process, Trainer.py:127-143)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return stats_stage_run, n_els_epoch
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    keys = list(_LOWER_IS_BETTER)
+    vec = torch.stack([torch.as_tensor(stats_stage_run[f"{k}_run"], dtype=torch.float64, device=dev).reshape(()) for k in keys] +
+                      [torch.tensor(float(n_els_epoch), dtype=torch.float64, device=dev)])
+    dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    for k, v in zip(keys, vec[:-1].tolist()):
+        stats_stage_run[f"{k}_run"] = v
+    return stats_stage_run, int(round(vec[-1].item()))
+
+
 def end_of_epoch_stats_update(stats_stage_run: dict, stats_stage_best: dict, n_els_epoch: int, n_steps: int):
+    stats_stage_run, n_els_epoch = _sum_over_ranks(stats_stage_run, n_els_epoch)
     for key in _LOWER_IS_BETTER:
         stats_stage_run[f"{key}_run"] = float(stats_stage_run[f"{key}_run"]) / max(n_els_epoch, 1)   # one sync per epoch
     stats_stage_run["padding_tokens_pct_run"] /= max(n_steps, 1)

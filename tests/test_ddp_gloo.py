@@ -84,3 +84,41 @@ def test_gradsync_single_process_is_a_noop_wrapper():
     sync.finish()
     for p in model.parameters():
         assert p.grad is not None and p.grad.data_ptr() >= sync.buckets[0].flat.data_ptr()
+
+
+def _stats_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kindergarten-vq-vae_amd"))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from models.shelgon3.Trainer import end_of_epoch_stats_update, init_stats_best, init_stats_run
+    run = init_stats_run()
+    n = 10 + 5 * rank                                         # ranks saw different numbers of sentences
+    run["loss_recon_run"] = torch.tensor(2.0 * (rank + 1)) * n
+    run["loss_vq_run"] = 0.5 * n
+    run["metric_acc_run"] = torch.tensor(50.0 + 10 * rank) * n
+    run["metric_perp_run"] = 7.0 * n
+    run["loss_full_run"] = run["loss_recon_run"] + run["loss_vq_run"]
+    stats, best = end_of_epoch_stats_update(run, init_stats_best(), n, 3)
+    torch.save({k: float(v) for k, v in stats.items()}, os.path.join(out_dir, f"stats{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_epoch_statistics_are_global_means_on_every_rank(tmp_path):
+    """Trainer.end_of_epoch_stats_update under data parallelism: one all-reduce of the running sums, every rank reports the mean
+    over the whole split (what a single process would print and base its best-checkpoint decision on)."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_stats_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "stats0.pt"), torch.load(tmp_path / "stats1.pt")
+    assert a == b
+    want_recon = (2.0 * 10 + 4.0 * 15) / 25
+    assert abs(a["loss_recon_run"] - want_recon) < 1e-9 and abs(a["loss_vq_run"] - 0.5) < 1e-9
+    assert abs(a["metric_acc_run"] - (50.0 * 10 + 60.0 * 15) / 25) < 1e-9 and abs(a["metric_perp_run"] - 7.0) < 1e-9
