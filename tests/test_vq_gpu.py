@@ -321,3 +321,24 @@ def test_kmeans_update_keeps_empty_clusters_and_counts():
         KF.kmeans2_points(z, 2000)
     with pytest.raises(KvqError):
         KF.kmeans2_points(z.cpu(), 4)
+
+
+def test_nine_codebooks_full_size_equals_separate_launches(kvq):
+    """BASELINE configs[4] shape of the quantiser: 9 factor codebooks x K = 512, D = 768, N = 8192 bf16 tokens each.
+    One grouped launch must equal nine single-codebook launches bit for bit (indices, z_q, losses, histograms, gradients)."""
+    torch.manual_seed(9)
+    G, N, K, D = 9, 8192, 512, 768
+    z = torch.randn(G, N, D, device="cuda").bfloat16().requires_grad_(True)
+    E = torch.randn(G, K, D, device="cuda").requires_grad_(True)
+    loss, z_q, perp, idx, counts = kvq.vector_quantize(z, E, 0.25)
+    assert idx.shape == (G, N) and z_q.shape == (G, N, D) and counts.shape == (G, K)
+    gq = torch.randn(G, N, D, device="cuda").bfloat16()
+    (loss.sum() + (z_q.float() * gq.float()).sum()).backward()
+    for g in range(G):
+        zg = z[g].detach().clone().requires_grad_(True); Eg = E[g].detach().clone().requires_grad_(True)
+        l1, zq1, p1, i1, c1 = kvq.vector_quantize(zg, Eg, 0.25)
+        assert torch.equal(i1, idx[g]) and torch.equal(zq1, z_q[g]) and torch.equal(c1, counts[g])
+        assert l1.item() == loss[g].item() and p1.item() == perp[g].item()
+        (l1 + (zq1.float() * gq[g].float()).sum()).backward()
+        assert torch.equal(zg.grad, z.grad[g]) and torch.equal(Eg.grad, E.grad[g])
+    assert counts.sum().item() == G * N
