@@ -10,7 +10,7 @@ Differences by design:
     ("bert-base-uncased", ...) is built from its architecture config with random init -- the reference fetches
     weights by name (Bagon.py:25-27), there is no network here;
   * forward runs kvq.bert's fused plan in bf16 (f32 master weights) instead of HF's module-by-module forward;
-    `backend="hf"` keeps HF's own forward reachable (it is the oracle in tests/test_bert_parity.py).
+    `backend="hf"` keeps HF's own forward reachable (it is the oracle in tests/test_abi_and_host.py::test_bert_plan_equals_huggingface_forward and tests/test_engine_gpu.py::test_hf_forward_kvq_path_and_engine_agree_on_gpu).
 """
 from __future__ import annotations
 

@@ -218,3 +218,27 @@ def test_engine_graphs_per_shape_interleaved_with_eval():
         assert len(eng._graphs) == (2 if use_graph else 0) and eng.step_count == 9
         runs.append(out)
     np.testing.assert_allclose(runs[0], runs[1], rtol=2e-2, atol=2e-3)
+
+
+def test_hf_forward_kvq_path_and_engine_agree_on_gpu():
+    """The chain that pins the composed step: HuggingFace's own BERT forward (the third-party part of the reference, Bagon.py:46-55)
+    -> the kvq path of the same modules (HIP LayerNorm / attention / GELU kernels) -> the TrainEngine, all on the GPU in f32 eval
+    mode on one model: same logits, same reconstruction loss."""
+    from kvq.engine import TrainEngine
+    from kvq.functional import fused_cross_entropy
+    model = _build(torch.float32).eval()
+    ids, mask = _batch(B=5, S=12, seed=21)
+    with torch.no_grad():
+        model.backend = "hf"
+        vq_hf, perp_hf, idx_hf, logits_hf = model(ids, mask)
+        model.backend = "kvq"
+        vq_kv, perp_kv, idx_kv, logits_kv = model(ids, mask)
+    assert torch.equal(idx_hf, idx_kv)
+    torch.testing.assert_close(logits_kv, logits_hf, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(vq_kv.item(), vq_hf.item(), rtol=1e-5)
+    loss_hf, _, pred_hf = fused_cross_entropy(logits_hf.reshape(-1, logits_hf.shape[-1]).contiguous(), ids.reshape(-1))
+    eng = TrainEngine(model)
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=False)
+    np.testing.assert_allclose(out["loss_recon"].item(), loss_hf.item(), rtol=2e-5)
+    np.testing.assert_allclose(out["loss_vq"].item(), vq_hf.item(), rtol=1e-5)
+    assert torch.equal(out["indices"], idx_hf) and torch.equal(out["recon_ids"].reshape(-1), pred_hf)
