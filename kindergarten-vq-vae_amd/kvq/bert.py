@@ -32,7 +32,7 @@ def _layer_norm(x, ln, dtype):
 def _embeddings(emb, input_ids, dtype, p_drop, training):
     """BertEmbeddings.forward (:68-108): word + token_type(0) + absolute position, LayerNorm, dropout."""
     B, S = input_ids.shape
-    x = F.embedding(input_ids, emb.word_embeddings.weight)
+    x = F.embedding(input_ids, emb.word_embeddings.weight, padding_idx=emb.word_embeddings.padding_idx)   # pad row: no gradient (modeling_bert.py:60)
     x = x + emb.token_type_embeddings.weight[0] + emb.position_embeddings.weight[:S]
     x = _layer_norm(x.to(dtype), emb.LayerNorm, dtype)
     return F.dropout(x, p_drop, training)

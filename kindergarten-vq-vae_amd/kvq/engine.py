@@ -317,6 +317,10 @@ class TrainEngine:
             raise KvqError("TrainEngine expects the LM head tied to the decoder word embeddings (HF default)")
         # parameters the step never touches (pooler) stay outside the flat buffers and receive no gradient
         self.flat = FlatParams(entries, dev, self.dtype, amsgrad)
+        pads = {enc.embeddings.word_embeddings.padding_idx, dec.bert.embeddings.word_embeddings.padding_idx}
+        if len(pads) != 1:
+            raise KvqError("TrainEngine expects the same padding_idx in the encoder and decoder word embeddings")
+        self._pad_idx = pads.pop()
         self.n_enc_layers = len(enc.encoder.layer)
         self.n_dec_layers = len(dec.bert.encoder.layer)
         self.nh = self.ecfg.num_attention_heads
@@ -506,13 +510,20 @@ class TrainEngine:
             if g_y.shape[1] % 4 == 0 and g_y.shape[1] <= 1024:
                 # deterministic segmented sum over the tokens sorted by id (one stable sort per step serves both tables)
                 if self._sorted_ids is None:
-                    self._sorted_ids = torch.sort(ids.reshape(-1), stable=True)
+                    # nn.Embedding(padding_idx = pad token) of BertEmbeddings (modeling_bert.py:60): the pad row receives no
+                    # gradient from the lookups -- its tokens are sorted under id -1, which kvq_embed_grad ignores
+                    flat_ids = ids.reshape(-1)
+                    if self._pad_idx is not None:
+                        flat_ids = torch.where(flat_ids == self._pad_idx, torch.full_like(flat_ids, -1), flat_ids)
+                    self._sorted_ids = torch.sort(flat_ids, stable=True)
                 if not tied_accumulate:
                     gw.zero_()
                 nnops.embed_grad(g_y, self._sorted_ids[1], self._sorted_ids[0], gw, accumulate=tied_accumulate)
             else:
                 acc = torch.zeros(shape, dtype=torch.float32, device=self.dev)
                 acc.index_add_(0, ids.reshape(-1), g_y.float())
+                if self._pad_idx is not None:
+                    acc[self._pad_idx] = 0
                 if tied_accumulate:
                     gw.add_(acc.to(gw.dtype))          # LM-head weight gradient is already in there
                 else:

@@ -242,3 +242,39 @@ def test_hf_forward_kvq_path_and_engine_agree_on_gpu():
     np.testing.assert_allclose(out["loss_recon"].item(), loss_hf.item(), rtol=2e-5)
     np.testing.assert_allclose(out["loss_vq"].item(), vq_hf.item(), rtol=1e-5)
     assert torch.equal(out["indices"], idx_hf) and torch.equal(out["recon_ids"].reshape(-1), pred_hf)
+
+
+def test_engine_gradients_match_autograd_through_huggingface_forward():
+    """Every parameter gradient of the engine's explicit backward against torch autograd through HuggingFace's own forward
+    (encoder -> VectorQuantizer -> decoder with cross-attention -> mean token cross-entropy, Trainer.py:94-105), f32, dropout off."""
+    import torch.nn.functional as F
+    from kvq.engine import TrainEngine
+    model = _build(torch.float32).eval()
+    ids, mask = _batch(B=6, S=12, seed=5)
+    eng = TrainEngine(model, lr=1e-3)
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+    mine = {name: eng.flat.g(name).float().clone() for name, p in eng.param_of.items() if p.requires_grad}
+    gE_mine = eng.gE.clone()
+    for p in model.parameters():
+        p.grad = None
+    model.backend = "hf"
+    vq_loss, _perp, idx, logits = model(ids, mask)
+    loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), ids.reshape(-1)) + vq_loss
+    loss.backward()
+    model.backend = "kvq"
+    np.testing.assert_allclose(out["loss_recon"].item() + out["loss_vq"].item(), loss.item(), rtol=2e-5)
+    assert torch.equal(out["indices"], idx)
+    worst = 0.0
+    for name, p in eng.param_of.items():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        if name.endswith("k.b"):                              # key-bias gradients are rounding noise (softmax shift invariance)
+            continue
+        ref = p.grad.float()
+        got = mine[name]
+        if ref.dim() == 2 and got.shape[0] > ref.shape[0]:     # padded LM-head rows
+            got = got[: ref.shape[0]]
+        torch.testing.assert_close(got, ref, rtol=5e-3, atol=5e-6, msg=lambda m: f"{name}: {m}")
+        worst = max(worst, (got - ref).abs().max().item())
+    torch.testing.assert_close(gE_mine, model.vector_quantizer.embedding.weight.grad, rtol=2e-3, atol=1e-7)
