@@ -671,6 +671,10 @@ __global__ __launch_bounds__(64) void embed_grad_runs_kernel(const void* __restr
     const int64_t b = blockIdx.x, s0 = b * EG_R;
     const int64_t s1 = s0 + EG_R < N ? s0 + EG_R : N;
     const int n = (int)(s1 - s0);
+    if (sid[s1 - 1] < 0 || sid[s0] >= V) {                   // ascending ids: the whole block is ignored ids (e.g. masked pad tokens)
+        if (lane == 0) meta[b] = 0;
+        return;
+    }
     // lane l keeps position s0 + l's id and token (lanes >= n mirror the last one)
     const int64_t my = s0 + (lane < n ? lane : n - 1);
     const long long my_id = sid[my], my_tok = perm[my];
