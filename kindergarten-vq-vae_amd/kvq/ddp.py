@@ -34,7 +34,11 @@ def init_distributed(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm.  KVQ_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+            # (all ranks then share the visible devices round-robin; the exchange goes through the host)
+            backend = os.environ.get("KVQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend != "nccl" and torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
