@@ -31,6 +31,12 @@ LOCAL_BERT_CONFIGS = {
     "kvq-bert-small": dict(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024),
     "kvq-bert-tiny": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                           vocab_size=2048, max_position_embeddings=64),
+    # bert-base widths (768 / 12 heads / 3072 / vocab 30522) with two layers: every GEMM shape of the benchmarked step
+    # at a size a parity test can afford (tests/test_engine_base_shapes_gpu.py)
+    "kvq-bert-base-2l": dict(num_hidden_layers=2),
+    # architecture of tests/golden/step_tiny.npz (tests/golden/make_step_golden.py::CFG)
+    "kvq-bert-fixture": dict(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256,
+                             vocab_size=512, max_position_embeddings=32),
 }
 
 

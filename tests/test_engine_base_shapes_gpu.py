@@ -1,0 +1,143 @@
+"""The TrainEngine at the GEMM shapes of the benchmarked step (BASELINE.json configs[1]): hidden 768, 12 heads, FFN 3072,
+vocabulary 30522 (padded to 30528 rows), >= 2048 tokens -- with two layers per stack so a parity test can afford it.
+These are the shapes at which the engine switches code paths (own MFMA GEMMs, split-K / grouped weight gradients, the
+all-layer cross-attention K/V GEMM, the padded LM head, 16-byte reduce paths); tests/test_engine_gpu.py's tiny model reaches
+none of them.  Reference: models/shelgon3/Shelgon.py:50-73 + models/shelgon3/Trainer.py:82-115, with HuggingFace's own
+forward + torch autograd (the third-party part of the reference) as the oracle for the BERT blocks.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+K_CODES = 512
+
+
+def _build(dtype, seed=0):
+    from models.shelgon3.Shelgon import Shelgon
+    from models.shelgon3.VectorQuantizer import VectorQuantizer
+    torch.manual_seed(seed)
+    vq = VectorQuantizer(K_CODES, 768, 0.25, vq_codebook_init_values=torch.randn(K_CODES, 768))    # well-separated codes
+    vq.materialize_min_encodings = False
+    model = Shelgon("kvq-bert-base-2l", vq, "kvq-bert-base-2l", None, compute_dtype=dtype).cuda()
+    model.set_mode("full")
+    return model.eval()
+
+
+def _batch(B=64, S=32, seed=1):
+    from dsentences.synthetic import random_token_batch
+    ids, mask = random_token_batch(B, S, torch.Generator().manual_seed(seed))
+    return ids.cuda(), mask.cuda()
+
+
+def _hf_autograd(model, ids, mask):
+    """loss + gradients of every parameter through HuggingFace's forward (f32)."""
+    for p in model.parameters():
+        p.grad = None
+    model.backend = "hf"
+    try:
+        vq_loss, perp, idx, logits = model(ids, mask)
+        l_rec = F.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), ids.reshape(-1))
+        (l_rec + vq_loss).backward()
+    finally:
+        model.backend = "kvq"
+    return dict(loss_recon=l_rec.item(), loss_vq=vq_loss.item(), perp=perp.item(), idx=idx.clone(),
+                recon=logits.argmax(-1).clone(),
+                grads={n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+
+def _engine_grads(eng, model):
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    out = {}
+    for ename, p in eng.param_of.items():
+        if p.requires_grad:
+            g = eng.flat.g(ename).float()
+            if g.dim() == 2 and g.shape[0] > p.shape[0]:
+                g = g[: p.shape[0]]
+            elif g.dim() == 1 and g.shape[0] > p.shape[0]:
+                g = g[: p.shape[0]]
+            out[name_of[id(p)]] = g.clone()
+    return out
+
+
+def test_engine_f32_at_bert_base_shapes_matches_autograd_through_huggingface():
+    from kvq.engine import TrainEngine
+    model = _build(torch.float32)
+    ids, mask = _batch()
+    assert ids.numel() >= 2048
+    eng = TrainEngine(model, lr=1e-4)
+    assert eng.Vp == 30528 and eng._cakv_batched
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+    mine = _engine_grads(eng, model)
+    gE = eng.gE.clone()
+    ref = _hf_autograd(model, ids, mask)
+    np.testing.assert_allclose(out["loss_recon"].item(), ref["loss_recon"], rtol=2e-5)
+    np.testing.assert_allclose(out["loss_vq"].item(), ref["loss_vq"], rtol=2e-5)
+    np.testing.assert_allclose(out["perplexity"].item(), ref["perp"], rtol=1e-4)
+    assert torch.equal(out["indices"], ref["idx"])
+    assert (out["recon_ids"] != ref["recon"]).float().mean().item() < 1e-3      # arg-max over 30522 near-equal random logits
+    checked = 0
+    for n, g in mine.items():
+        if n.endswith("key.bias"):              # rounding noise (softmax shift invariance)
+            continue
+        r = ref["grads"][n]
+        err = (g - r).norm().item() / max(r.norm().item(), 1e-30)
+        assert err < 2e-3, f"{n}: relative L2 error {err:.3g}"
+        checked += 1
+    assert checked > 60, checked
+    torch.testing.assert_close(gE, model.vector_quantizer.embedding.weight.grad, rtol=2e-3, atol=1e-7)
+
+
+def test_engine_bf16_at_bert_base_shapes(monkeypatch):
+    """bf16 product path (own GEMMs on) against (a) f32 autograd through HuggingFace's forward and (b) the same engine with
+    every GEMM routed to the vendor library: (b) isolates the hand-written GEMM kernels from bf16 rounding."""
+    from kvq.engine import TrainEngine
+    ids, mask = _batch(seed=2)
+    m32 = _build(torch.float32)
+    ref = _hf_autograd(m32, ids, mask)
+    del m32
+    runs = {}
+    for own in ("1", "0"):
+        monkeypatch.setenv("KVQ_OWN_GEMM", own)
+        model = _build(torch.bfloat16)
+        eng = TrainEngine(model, lr=1e-4)
+        out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+        runs[own] = (dict(loss_recon=out["loss_recon"].item(), loss_vq=out["loss_vq"].item(), idx=out["indices"].clone()),
+                     _engine_grads(eng, model), eng.gE.clone())
+        del eng, model
+        torch.cuda.empty_cache()
+    (o1, g1, e1), (o0, g0, e0) = runs["1"], runs["0"]
+    # (a) against f32 truth: bf16 tolerances
+    np.testing.assert_allclose(o1["loss_recon"], ref["loss_recon"], rtol=2e-2)
+    np.testing.assert_allclose(o1["loss_vq"], ref["loss_vq"], rtol=5e-2)
+    agree = (o1["idx"] == ref["idx"]).float().mean().item()
+    assert agree > 0.97, f"bf16 encoder output flips {100 * (1 - agree):.2f} % of the code indices"
+    cos = []
+    for n, g in g1.items():
+        r = ref["grads"][n]
+        if r.norm() > 0 and not n.endswith("key.bias"):
+            cos.append((n, F.cosine_similarity(g.reshape(-1), r.reshape(-1), dim=0).item()))
+    worst = min(cos, key=lambda t: t[1])
+    assert worst[1] > 0.9 and np.mean([c for _, c in cos]) > 0.99, (worst, np.mean([c for _, c in cos]))
+    # (b) own kernels against the library on the same bf16 inputs: only summation order differs
+    np.testing.assert_allclose(o1["loss_recon"], o0["loss_recon"], rtol=2e-3)
+    np.testing.assert_allclose(o1["loss_vq"], o0["loss_vq"], rtol=5e-3)
+    for n, g in g1.items():
+        if n.endswith("key.bias"):
+            continue
+        r = g0[n]
+        err = (g - r).norm().item() / max(r.norm().item(), 1e-30)
+        assert err < 3e-2, f"{n}: own-GEMM vs library relative L2 difference {err:.3g}"
+
+
+def test_engine_graph_step_at_bert_base_shapes_trains():
+    """Three eager + three replayed steps (hipGraph) at these shapes with dropout on: finite, decreasing loss."""
+    from kvq.engine import TrainEngine
+    model = _build(torch.bfloat16).train()
+    eng = TrainEngine(model, lr=2e-4)
+    ids, mask = _batch(seed=3)
+    losses = [float(eng.train_step(ids, mask)["loss_recon"]) for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    assert eng._graphs, "the step was not captured"
