@@ -255,6 +255,37 @@ int kvq_gemm_nt_bf16_gelu(const void* A, const void* B, const void* bias, void* 
 int kvq_gemm_nt_bf16_dgelu(const void* A, const void* B, const void* H, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                            void* stream);
 
+/* ---- bf16 MFMA GEMM family, all three operand layouts of one nn.Linear's forward / backward (csrc/kvq_gemm2.hip) ----------
+ * Replaces, for y = x . W^T + b of every BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput / LM-head linear
+ * reached from models/bagon/Bagon.py:46-53 and models/shelgon3/Shelgon.py:52,71 (modeling_bert.py:139-352,483-497):
+ *   KVQ_GEMM_NT  C[M,N] = A[M,K] . B[N,K]^T     forward        (x, W)         torch: F.linear
+ *   KVQ_GEMM_NN  C[M,N] = A[M,K] . B[K,N]       input gradient (gy, W)        autograd: grad_output.mm(weight)
+ *   KVQ_GEMM_TN  C[M,N] = A[K,M]^T . B[K,N]     weight gradient (gy, x)       autograd: grad_output.t().mm(input)
+ * bf16 operands and result, f32 accumulation (v_mfma_f32_16x16x32_bf16), optional bias[N] (bf16) and C += (accumulate != 0).
+ * K %% 64 == 0; M, N, lda, ldb, ldc %% 8 == 0; 16-byte aligned operands; row-major with the given leading dimensions.
+ * `tile` picks the workgroup tile: the caller chooses it so that the tile count fills the 256 CUs.
+ * A grouped launch runs up to 8 problems of ONE layout as a single grid (e.g. the four weight gradients of a BERT layer:
+ * ~250 tiles of 128 x 256, one per CU over the whole token contraction -- no split-K, no partial slabs). */
+#define KVQ_GEMM_NT 0
+#define KVQ_GEMM_NN 1
+#define KVQ_GEMM_TN 2
+#define KVQ_GEMM_TILE_128x192 0   /* 4 waves; 256 tiles for [8192, 768] outputs */
+#define KVQ_GEMM_TILE_128x256 1   /* 8 waves */
+#define KVQ_GEMM_TILE_256x192 2   /* 8 waves */
+#define KVQ_GEMM_TILE_256x256 3   /* 8 waves */
+typedef struct kvq_gemm_problem {
+    const void* A;
+    const void* B;
+    void* C;
+    const void* bias;     /* bf16 [N] or NULL */
+    int M, N, K;
+    int lda, ldb, ldc;
+    int accumulate;
+} kvq_gemm_problem;
+int kvq_gemm_bf16(const void* A, const void* B, const void* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                  int layout, int tile, int accumulate, void* stream);
+int kvq_gemm_grouped_bf16(const kvq_gemm_problem* problems, int n_problems, int layout, int tile, void* stream);
+
 /* torch.optim.Adam step (models/shelgon3/main.py:91: lr, weight_decay (L2, coupled), amsgrad) on flat buffers.
  *   p, m, v [, vmax] f32; g grad_dtype (scaled by grad_scale first); shadow_bf16 (may be NULL) receives bf16(p_new).
  *   step >= 1 is the 1-based step count for bias correction.  n %% 4 == 0. */

@@ -24,6 +24,15 @@ class ReduceItem(C.Structure):
                 ("src_dtype", C.c_int32), ("dst_dtype", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class GemmProblem(C.Structure):
+    """struct kvq_gemm_problem of include/kvq.h"""
+    _fields_ = [("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("M", _int), ("N", _int), ("K", _int),
+                ("lda", _int), ("ldb", _int), ("ldc", _int), ("accumulate", _int)]
+
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+GEMM_TILE_128x192, GEMM_TILE_128x256, GEMM_TILE_256x192, GEMM_TILE_256x256 = 0, 1, 2, 3
+
 # name -> (restype, argtypes); mirrors include/kvq.h line by line
 SIGNATURES = {
     "kvq_version": (_int, []),
@@ -71,6 +80,8 @@ SIGNATURES = {
                             C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
     "kvq_gemm_nt_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_set_stages": (_int, [_int]),
+    "kvq_gemm_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "kvq_gemm_grouped_bf16": (_int, [C.POINTER(GemmProblem), _int, _int, _int, _vp]),
     "kvq_transpose_batch_bf16": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int, _int, _int, _vp]),
     "kvq_gemm_nt_bf16_gelu": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_nt_bf16_dgelu": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),

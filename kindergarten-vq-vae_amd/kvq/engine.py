@@ -244,6 +244,9 @@ class TrainEngine:
         self._step_seed = (self.seed * 1000003) & 0x7FFFFFFFFFFFFFF      # + step count on the device
         self._graphs, self._eager_seen, self._cap = {}, {}, None
         self._own_fwd = os.environ.get("KVQ_OWN_GEMM", "1") != "0"
+        # weight gradients of a whole layer as ONE grouped launch of csrc/kvq_gemm2.hip (KVQ_OWN_WGRAD=0: library + split-K slabs)
+        self._own_wgrad = self._own_fwd and os.environ.get("KVQ_OWN_WGRAD", "1") != "0" and self.dtype == torch.bfloat16
+        self._wg_items, self._wg_keep = [], []
         # opt-in (KVQ_WG_STREAM=1): weight-gradient GEMMs on a side stream.  Measured on MI355X with the step replayed from
         # hipGraphs: 23.6 ms/step against 22.5 ms on one stream -- two concurrent hipBLASLt kernels share CUs and L2 badly
         self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get("KVQ_WG_STREAM", "0") == "1" else None
@@ -342,17 +345,6 @@ class TrainEngine:
         self._ev_early = torch.cuda.Event() if self.world > 1 else None
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         _load_gemm_tuning()
-        # W^T beside every square projection weight of the _OWN_GEMM shapes (bf16 only): their input-gradient GEMM then runs
-        # as an NT product on csrc/kvq_gemm.hip; one batched transpose per optimiser step keeps the copies current
-        self._wT, self._wT_op = {}, None
-        if self.dtype == torch.bfloat16 and os.environ.get("KVQ_OWN_DGRAD", "0") == "1":
-            names = [n for n, (_o, _n, shape) in self.flat.seg.items()
-                     if len(shape) == 2 and tuple(shape) in self._OWN_GEMM and shape[0] == shape[1] and n.endswith(".w")
-                     and ".sa.q." not in n and ".sa.k." not in n and ".sa.v." not in n and ".ca.k." not in n and ".ca.v." not in n]
-            if names:
-                self._wT = {n: torch.empty(tuple(self.flat.seg[n][2]), dtype=torch.bfloat16, device=dev) for n in names}
-                self._wT_op = nnops.TransposeBatch([self.flat.w(n) for n in names], [self._wT[n] for n in names])
-                self._wT_op.run()
 
     # ------------------------------------------------------------------------------------------------------------
     # small helpers
@@ -377,15 +369,19 @@ class TrainEngine:
         self._site_ctr += 1
         return self._site_ctr
 
-    # (N, K) of the forward projections where csrc/kvq_gemm.hip beats the tuned library (tools/gemm_own_probe.py on MI355X:
-    # 8192x768x768 17.2 us vs 20.7 us); every other shape stays with hipBLASLt
-    _OWN_GEMM = {(768, 768)}
+    # (N, K) -> workgroup tile of csrc/kvq_gemm2.hip for the shapes where it beats the tuned library at 8192 rows
+    # (tools/gemm2_probe.py on MI355X, interleaved rounds; gpurun_out/g2_probe*.log); every other shape stays with hipBLASLt
+    _OWN_FWD = {(768, 768): "128x256"}                                          # y = x . W^T + b        ("nt")
+    _OWN_DGRAD = {(768, 768): "128x256", (768, 3072): "128x256", (3072, 768): "256x192", (768, 18432): "128x256"}   # gx = gy . W ("nn")
+    _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "256x192"}      # gW = gy^T . x          ("tn"), own launch
 
     def _linear(self, x, wname, bname, fused=None):
         W = self.flat.fused(fused[0], self.flat.shadow) if fused else self.flat.w(wname)
         b = self.flat.fused(fused[1], self.flat.shadow) if fused else self.flat.w(bname)
-        if self._own_fwd and self.dtype == torch.bfloat16 and tuple(W.shape) in self._OWN_GEMM and x.shape[0] >= 2048 and x.is_contiguous():
-            return nnops.gemm_nt(x, W, b)
+        if self._own_fwd and self.dtype == torch.bfloat16 and x.shape[0] >= 2048 and x.stride(1) == 1:
+            tile = self._OWN_FWD.get(tuple(W.shape))
+            if tile is not None:
+                return nnops.gemm(x, W, "nt", bias=b, tile=tile)
         return torch.addmm(b, x, W.t())
 
     # split-K factors for the weight-gradient GEMMs gW[M,N] = gy[Ntok,M]^T x[Ntok,N]: the contraction (Ntok = 8192) is long
@@ -401,7 +397,17 @@ class TrainEngine:
         self._red_items.append(nnops.reduce_item(src, dst, count, cols, ld, src_offset=src_offset))
         self._red_keep.append(src)            # the partials must outlive the launch
 
+    def _flush_wgrads(self):
+        """The weight gradients queued since the last flush (one layer's worth) as one grouped launch: ~250 tiles of 128 x 256,
+        one per CU over the whole token contraction, written straight into the flat bf16 gradient buffer."""
+        items = self._wg_items
+        for i in range(0, len(items), 8):
+            nnops.gemm_grouped(items[i:i + 8], "tn", "128x256")
+        self._wg_items, self._wg_keep = [], []
+
     def _flush_reductions(self):
+        if self._wg_items:
+            self._flush_wgrads()
         if self._wg_pending:                     # weight-gradient GEMMs of this layer ran on the side stream: join it first
             torch.cuda.current_stream(self.dev).wait_stream(self.wg_stream)
             self._wg_pending = False
@@ -447,6 +453,15 @@ class TrainEngine:
     def _wgrad_on_current_stream(self, gy, x, out):
         Ntok, M = gy.shape
         N = x.shape[1]
+        if self._own_wgrad and Ntok % 64 == 0 and Ntok >= 2048 and gy.stride(1) == 1 and x.stride(1) == 1 and out.stride(1) == 1 \
+                and M % 8 == 0 and N % 8 == 0:
+            single = self._OWN_WGRAD_SINGLE.get((M, N))
+            if single is not None:
+                nnops.gemm(gy, x, "tn", out=out, tile=single)
+            else:
+                self._wg_items.append(nnops.gemm_problem(gy, x, out, "tn"))
+                self._wg_keep += [gy, x]                       # alive until the grouped launch
+            return
         S = self._SPLITS.get((M, N), 0) if self.dtype == torch.bfloat16 else 0
         if S and Ntok % S == 0 and Ntok // S >= 256 and gy.is_contiguous() and x.is_contiguous():
             part = torch.bmm(gy.view(S, Ntok // S, M).transpose(1, 2), x.view(S, Ntok // S, N))
@@ -465,13 +480,10 @@ class TrainEngine:
             self._wgrad(gy, x, gW)
         if fl.trainable[bnames[0]] and not bias_done:     # bias_done: the LayerNorm backward kernel already produced it
             self._defer_colsum(gy, gb)
-        WT = self._wT.get(wnames[0]) if len(wnames) == 1 else None
-        if WT is not None and gy.shape[0] >= 2048 and gy.is_contiguous() and (need_gx or gx_accum is not None):
-            # g . W as the NT product g . (W^T)^T on the transposed shadow copy: the shape where kvq_gemm.hip beats the library
-            if gx_accum is not None and not gx_accum.is_contiguous():
-                WT = None
-            else:
-                return nnops.gemm_nt(gy, WT, None, out=gx_accum, accumulate=gx_accum is not None)
+        if self._own_fwd and self.dtype == torch.bfloat16 and gy.shape[0] >= 2048 and gy.stride(1) == 1 and (need_gx or gx_accum is not None):
+            tile = self._OWN_DGRAD.get((W.shape[1], W.shape[0]))
+            if tile is not None and (gx_accum is None or gx_accum.stride(1) == 1):
+                return nnops.gemm(gy, W, "nn", out=gx_accum, accumulate=gx_accum is not None, tile=tile)
         if gx_accum is not None:
             gx_accum.addmm_(gy, W)
             return gx_accum
@@ -710,6 +722,7 @@ class TrainEngine:
             raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
         self._site_ctr = 0
         self._red_items, self._red_keep = [], []
+        self._wg_items, self._wg_keep = [], []
         self._sorted_ids = None
         nnops.set_seed_offset(self._state)        # dropout seeds of this engine's launches = _step_seed + device step count
         try:
@@ -896,15 +909,11 @@ class TrainEngine:
         if self.has_vq and self.E.requires_grad:
             nnops.adam_step_dev(self.E.data.view(-1), self.gE.view(-1), self.mE.view(-1), self.vE.view(-1), self._state,
                                 b1, b2, self.eps, self.wd, vmax=self.vmaxE.view(-1) if self.vmaxE is not None else None)
-        if self._wT_op is not None:
-            self._wT_op.run()
 
     def sync_from_model(self):
         """Call after the model's parameters were written from outside (load_state_dict, manual init): refreshes the bf16
         shadow weights the GEMMs read.  (The f32 master buffer IS the parameters' storage, nothing to copy there.)"""
         self.flat.refresh_shadow()
-        if self._wT_op is not None:
-            self._wT_op.run()
 
     @staticmethod
     def supports(model, seq_len: int) -> bool:
@@ -958,6 +967,7 @@ class TrainEngine:
                 self._works, self._works_late = [], []
             self._pending_hi = self.flat.n
         self._red_items, self._red_keep, self._wg_pending = [], [], False
+        self._wg_items, self._wg_keep = [], []
 
     def eval_step(self, input_ids, attention_mask):
         return self.forward_backward(input_ids, attention_mask, training=False, compute_grads=False)

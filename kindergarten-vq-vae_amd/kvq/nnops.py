@@ -270,3 +270,63 @@ def gemm_nt_dgelu(a, b, h):
     check(lib().kvq_gemm_nt_bf16_dgelu(a.data_ptr(), b.data_ptr(), h.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
                                        out.stride(0), stream_ptr()), "kvq_gemm_nt_bf16_dgelu")
     return out
+
+
+# ---- the GEMM family of csrc/kvq_gemm2.hip ---------------------------------------------------------------------------------
+_LAYOUTS = {"nt": 0, "nn": 1, "tn": 2}
+TILES = {"128x192": 0, "128x256": 1, "256x192": 2, "256x256": 3}
+_TILE_DIMS = {0: (128, 192), 1: (128, 256), 2: (256, 192), 3: (256, 256)}
+
+
+def _gemm_dims(a, b, layout):
+    if layout == "nt":
+        (M, K), N = a.shape, b.shape[0]
+    elif layout == "nn":
+        (M, K), N = a.shape, b.shape[1]
+    else:
+        (K, M), N = a.shape, b.shape[1]
+    return M, N, K
+
+
+def pick_tile(M, N, n_cu=256):
+    """Workgroup tile for an [M, N] output: the candidate whose tile count wastes the least of the last round of 256 CUs,
+    larger tiles (more FLOP per staged byte) winning ties."""
+    best, best_key = 0, None
+    for t, (bm, bn) in _TILE_DIMS.items():
+        n = -(-M // bm) * -(-N // bn)
+        rounds = -(-n // n_cu)
+        eff = (M * N) / (rounds * n_cu * bm * bn)               # useful fraction of the MFMA slots of all rounds
+        key = (round(eff, 2), bm * bn)
+        if best_key is None or key > best_key:
+            best, best_key = t, key
+    return best
+
+
+def gemm_problem(a, b, out, layout, bias=None, accumulate=False):
+    from ._ffi import GemmProblem
+    M, N, K = _gemm_dims(a, b, layout)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+    assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1 and tuple(out.shape) == (M, N)
+    return GemmProblem(a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                       int(accumulate))
+
+
+def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
+    """out[M,N] (= | +=) op(a) @ op(b) (+ bias), bf16 with f32 accumulation on the MFMA GEMM of csrc/kvq_gemm2.hip.
+    layout "nt": a[M,K], b[N,K];  "nn": a[M,K], b[K,N];  "tn": a[K,M], b[K,N]."""
+    require_gpu(a, b)
+    M, N, K = _gemm_dims(a, b, layout)
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    t = pick_tile(M, N) if tile is None else (TILES[tile] if isinstance(tile, str) else tile)
+    check(lib().kvq_gemm_bf16(a.data_ptr(), b.data_ptr(), _p(bias), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                              _LAYOUTS[layout], t, int(accumulate), stream_ptr()), "kvq_gemm_bf16")
+    return out
+
+
+def gemm_grouped(problems, layout, tile):
+    """One launch over a list of gemm_problem()s of one layout (at most 8)."""
+    from ._ffi import GemmProblem
+    arr = (GemmProblem * len(problems))(*problems)
+    t = TILES[tile] if isinstance(tile, str) else tile
+    check(lib().kvq_gemm_grouped_bf16(arr, len(problems), _LAYOUTS[layout], t, stream_ptr()), "kvq_gemm_grouped_bf16")

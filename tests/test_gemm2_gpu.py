@@ -1,0 +1,101 @@
+"""csrc/kvq_gemm2.hip (kvq_gemm_bf16 / kvq_gemm_grouped_bf16) against torch f32 matmuls of the same bf16 operands: all three
+layouts of an nn.Linear's forward / input gradient / weight gradient (modeling_bert.py:139-352 behind Bagon.py:46-53), every
+workgroup tile, ragged edges, strided operands, bias, accumulate, grouped launches."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TILES = ["128x192", "128x256", "256x192", "256x256"]
+
+
+def _ops(layout, M, N, K, seed=0, lda_pad=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    def rnd(r, c, pad=0):
+        t = torch.randn((r, c + pad), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+        return t[:, :c] if pad else t
+    if layout == "nt":
+        a, b = rnd(M, K, lda_pad), rnd(N, K)
+        ref = a.float() @ b.float().t()
+    elif layout == "nn":
+        a, b = rnd(M, K, lda_pad), rnd(K, N)
+        ref = a.float() @ b.float()
+    else:
+        a, b = rnd(K, M, lda_pad), rnd(K, N)
+        ref = a.float().t() @ b.float()
+    return a, b, ref
+
+
+def _check(out, ref, K):
+    # bf16 output rounding (2^-9 relative) on values of magnitude ~sqrt(K)
+    err = (out.float() - ref).abs().max().item()
+    tol = 2.0 ** -8 * ref.abs().max().item() + 1e-3
+    assert err <= tol, (err, tol)
+    rel = (out.float() - ref).norm().item() / ref.norm().item()
+    assert rel < 3e-3, rel
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("shape", [(512, 768, 256), (1000, 776, 192), (264, 200, 64), (8, 8, 128), (1024, 3072, 768)])
+def test_gemm_layouts_tiles_and_edges(layout, tile, shape):
+    from kvq import nnops
+    M, N, K = shape
+    a, b, ref = _ops(layout, M, N, K, seed=M + N)
+    out = nnops.gemm(a, b, layout, tile=tile)
+    _check(out, ref, K)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_bias_accumulate_strides(layout):
+    from kvq import nnops
+    M, N, K = 640, 392, 320
+    a, b, ref = _ops(layout, M, N, K, seed=5, lda_pad=24)
+    bias = torch.randn(N, device="cuda").to(torch.bfloat16)
+    big = torch.randn((M, N + 40), device="cuda").to(torch.bfloat16)
+    out = big[:, 8:8 + N]                                      # row stride N + 40, offset 16 bytes
+    before = out.float().clone()
+    nnops.gemm(a, b, layout, bias=bias, out=out, accumulate=True)
+    want = (ref + bias.float()).to(torch.bfloat16).float() + before          # kernel rounds the product, then adds C in f32
+    err = (out.float() - want).abs().max().item()
+    assert err <= 2.0 ** -7 * want.abs().max().item(), err
+    assert torch.equal(big[:, :8], big[:, :8]) and torch.isfinite(big.float()).all()
+
+
+def test_gemm_does_not_touch_memory_outside_the_output():
+    from kvq import nnops
+    M, N, K = 200, 136, 128
+    a, b, ref = _ops("nt", M, N, K, seed=9)
+    big = torch.full((M + 2, N + 16), 7.0, device="cuda", dtype=torch.bfloat16)
+    out = big[1:M + 1, 8:8 + N]
+    nnops.gemm(a, b, "nt", out=out)
+    _check(out, ref, K)
+    assert (big[0] == 7).all() and (big[-1] == 7).all() and (big[:, :8] == 7).all() and (big[:, 8 + N:] == 7).all()
+
+
+@pytest.mark.parametrize("tile", ["128x256", "128x192"])
+def test_grouped_weight_gradients_of_one_layer(tile):
+    """The engine's per-layer launch: four TN problems (QKV, attention output, FFN1, FFN2 weight gradients) in one grid."""
+    from kvq import nnops
+    T = 1024
+    g = torch.Generator(device="cuda").manual_seed(1)
+    probs, outs, refs = [], [], []
+    for (m, n) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
+        gy = torch.randn((T, m), generator=g, device="cuda").to(torch.bfloat16)
+        x = torch.randn((T, n), generator=g, device="cuda").to(torch.bfloat16)
+        out = torch.empty((m, n), device="cuda", dtype=torch.bfloat16)
+        probs.append(nnops.gemm_problem(gy, x, out, "tn"))
+        outs.append(out); refs.append(gy.float().t() @ x.float())
+        outs.append(gy); outs.append(x)            # keep alive
+    nnops.gemm_grouped(probs, "tn", tile)
+    for i, r in enumerate(refs):
+        _check(outs[3 * i], r, T)
+
+
+def test_gemm_rejects_bad_arguments():
+    from kvq import nnops
+    from kvq._ffi import KvqError
+    a = torch.zeros((64, 100), device="cuda", dtype=torch.bfloat16)
+    b = torch.zeros((64, 100), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(KvqError):
+        nnops.gemm(a, b, "nt")                      # K = 100 is not a multiple of 64
