@@ -50,16 +50,37 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run,
+    rendezvous on 127.0.0.1) BEFORE this process has touched the GPU, hand their output through and exit with their code."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()            # does not initialise the GPU
+    if n_dev < a.gpus and os.environ.get("KVQ_DIST_BACKEND") != "gloo":
+        print(f"[bench] --gpus {a.gpus} but only {n_dev} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
     from kvq import _ffi, ddp
     from dsentences.synthetic import random_token_batch
     from models.shelgon3.Shelgon import Shelgon
     from models.shelgon3.VectorQuantizer import VectorQuantizer
 
     rank, local, world = ddp.init_distributed()
-    if world != a.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != a.gpus:
+        raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a number for a different job size")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     dev = torch.device("cuda", local)
@@ -115,6 +136,8 @@ def main():
         one_step(i)
     torch.cuda.synchronize()
     lib.kvq_prof_enable(a.steps + 4)
+    if engine is not None:
+        engine.reset_comm_timing()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -127,6 +150,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     final_loss = float(loss)
+    rccl_ranks, exposed_ms = 1, 0.0
+    if world > 1:
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                                  # the ranks that actually take part in a collective
+        rccl_ranks = int(probe.item())
+        if engine is not None:
+            exposed_ms = engine.exposed_comm_ms() / max(a.steps, 1)
 
     buf = (ctypes.c_float * (a.steps + 4))()
     n_ev = lib.kvq_prof_read(buf, a.steps + 4)
@@ -165,6 +195,9 @@ def main():
                                    f"batch={a.batch}/GPU, mode={a.mode}, Adam, dropout on, path={a.path}",
                        "global_batch": world * a.batch, "seq_len": a.seq_len, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
+            "graph": bool(engine is not None and engine._graphs),      # False = the step ran as ~800 eager launches (capture failed or off)
+            "rccl_ranks": rccl_ranks, "dist_backend": (dist.get_backend() if world > 1 else None),
+            "exposed_comm_ms_per_step": exposed_ms,
             "roofline": {
                 "kernel": "vq_dist_packed_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": (ach_tflops / F32_MFMA_PEAK_TFLOPS) if ach_tflops else None,

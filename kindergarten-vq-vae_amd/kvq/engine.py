@@ -343,6 +343,8 @@ class TrainEngine:
         self._pending_hi = self.flat.n
         self._works, self._works_late = [], []
         self._ev_early = torch.cuda.Event() if self.world > 1 else None
+        self._time_comm = False
+        self._comm_ev = []                       # (start, end) event pairs around the points where the compute stream waits for RCCL
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         _load_gemm_tuning()
 
@@ -703,11 +705,34 @@ class TrainEngine:
             self._all_reduce_avg(self.flat.grad[:cut], late=True)
         if self.has_vq:
             self._all_reduce_avg(self.gE, late=True)
-        torch.cuda.current_stream(self.dev).wait_event(self._ev_early)
+        self._timed_wait(lambda main: main.wait_event(self._ev_early))
 
     def _exchange_tail(self):
         self._settle(self._works_late)
-        torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
+        self._timed_wait(lambda main: main.wait_stream(self.comm_stream))
+
+    def _timed_wait(self, wait):
+        main = torch.cuda.current_stream(self.dev)
+        if not self._time_comm:
+            wait(main)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        wait(main)
+        e1.record(main)
+        self._comm_ev.append((e0, e1))
+
+    def reset_comm_timing(self, enable=True):
+        """Start (or stop) recording event pairs around the compute stream's waits for the gradient all-reduces."""
+        self._comm_ev, self._time_comm = [], bool(enable)
+
+    def exposed_comm_ms(self):
+        """Total time the compute stream spent blocked on gradient all-reduces since reset_comm_timing() (the two wait points of
+        a step: before Adam on the tail of the buffer, before Adam on its head).  Call after a device synchronisation."""
+        tot = 0.0
+        for e0, e1 in self._comm_ev:
+            tot += e0.elapsed_time(e1)
+        return tot
 
     # ------------------------------------------------------------------------------------------------------------
     # one training step

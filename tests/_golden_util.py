@@ -75,3 +75,16 @@ def check_indices(c, idx, max_ulps=8.0):
             f"{c['name']}: token {n}: chose code {idx[n]} (d={d[idx[n]]:.9g}) but minimum is {d.min():.9g} "
             f"at {d.argmin()} (reference chose {ref[n]}); gap {d[idx[n]] - d.min():.3g} > tol {tol:.3g}")
     return int(diff.size)
+
+
+# Tokens whose chosen code may differ from the reference's on a near-tie case (both being minimisers within 8 ulp, see
+# check_indices): the count measured when the fixtures were made (kvq order v1, oracle == HIP kernel bit for bit) plus slack.
+# Every committed case measures 0 -- including c2_default (N = 8192, 402 tokens with a top-2 gap below 1e-3, where the
+# reference itself differs from the fp64 arg-min on 9 tokens): a regression to a handful of flips must fail, not pass.
+MAX_NEAR_TIE_FLIPS = {"tiny_default": 0, "demo_default": 0, "c1_default": 0, "c2_default": 2}
+
+
+def check_flip_budget(c, ndiff):
+    budget = MAX_NEAR_TIE_FLIPS.get(c["name"], 0)
+    print(f"[golden] {c['name']}: {ndiff} of {c['B'] * c['S']} indices differ from the reference (budget {budget})")
+    assert ndiff <= budget, f"{c['name']}: {ndiff} index flips against the reference exceed the recorded budget of {budget}"

@@ -5,7 +5,7 @@ This is what pins the oracle: every other parity test compares the HIP path with
 import numpy as np
 import pytest
 
-from _golden_util import case_names, check_indices, load_case
+from _golden_util import case_names, check_flip_budget, check_indices, load_case
 from oracle import vq_oracle as O
 
 CASES = case_names()
@@ -21,6 +21,7 @@ def test_c_oracle_forward_matches_reference(name):
     c = load_case(name)
     out = O.vq_forward(c["z"], c["E"], float(c["beta"]))
     ndiff = check_indices(c, out["idx"])
+    check_flip_budget(c, ndiff)
     if c["regime"] in ("separated", "onto_codes", "ties"):
         assert ndiff == 0, f"{name}: {ndiff} index mismatches on a well-separated case"
     if ndiff == 0:

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden_util import case_names, check_indices, load_case
+from _golden_util import case_names, check_flip_budget, check_indices, load_case
 from oracle import vq_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -54,6 +54,7 @@ def test_forward_bit_exact_vs_oracle_and_reference(kvq, name):
     np.testing.assert_allclose(got["perplexity"], ora["perplexity"], rtol=1e-5)
     # HIP == reference golden: exact where the reference itself is stable, minimiser-within-ulps on near ties
     ndiff = check_indices(c, got["idx"])
+    check_flip_budget(c, ndiff)
     if c["regime"] != "default_init":
         assert ndiff == 0
     np.testing.assert_allclose(got["loss"], c["loss"], rtol=2e-6)
