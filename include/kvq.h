@@ -240,21 +240,6 @@ int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mas
  * kernels (f32 probabilities).  All flavours draw the same dropout mask.  f32 io always uses the f32 kernels. */
 int kvq_attn_set_variant(int variant);
 
-/* bf16 MFMA GEMM, "NT":  C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ C when accumulate != 0), bf16 in/out, f32 accumulation.
- * The shape of every forward projection x . W^T + b of the BERT blocks (modeling_bert.py:139-352) and, on a transposed
- * weight copy, of their input-gradient GEMMs.  K %% 64 == 0; N, lda, ldb, ldc %% 8 == 0; 16-byte aligned operands. */
-int kvq_gemm_nt_bf16(const void* A, const void* B, const void* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                     int accumulate, void* stream);
-/* LDS pipeline depth of the GEMM kernel: 2 (default; 64 KiB, 2 workgroups/CU) or 3 (two k-tiles in flight behind a counted
- * s_waitcnt vmcnt + raw s_barrier, 96 KiB, 1 workgroup/CU; measured 25-40 % slower on this model's shapes). */
-int kvq_gemm_set_stages(int stages);
-/* BertIntermediate in one kernel (modeling_bert.py:325-337): Hout = A.B^T + bias (saved for backward), Aout = gelu(Hout). */
-int kvq_gemm_nt_bf16_gelu(const void* A, const void* B, const void* bias, void* Hout, void* Aout, int M, int N, int K, int lda,
-                          int ldb, int ldc, void* stream);
-/* its backward through the activation: C = (A.B^T) * gelu'(H)   (A = gradient of BertOutput.dense's input, B = W2^T). */
-int kvq_gemm_nt_bf16_dgelu(const void* A, const void* B, const void* H, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                           void* stream);
-
 /* ---- bf16 MFMA GEMM family, all three operand layouts of one nn.Linear's forward / backward (csrc/kvq_gemm2.hip) ----------
  * Replaces, for y = x . W^T + b of every BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput / LM-head linear
  * reached from models/bagon/Bagon.py:46-53 and models/shelgon3/Shelgon.py:52,71 (modeling_bert.py:139-352,483-497):
@@ -285,6 +270,17 @@ typedef struct kvq_gemm_problem {
 int kvq_gemm_bf16(const void* A, const void* B, const void* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                   int layout, int tile, int accumulate, void* stream);
 int kvq_gemm_grouped_bf16(const kvq_gemm_problem* problems, int n_problems, int layout, int tile, void* stream);
+/* BertIntermediate in one kernel (modeling_bert.py:325-337), layout NT: Hout = A.B^T + bias (kept for backward) and
+ * Aout = gelu(Hout as rounded to bf16) -- exact-erf GELU (erf to 1.2e-7).  tile: KVQ_GEMM_TILE_256x192 or _128x256. */
+int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hout, void* Aout, int M, int N, int K, int lda, int ldb,
+                       int ldc, int tile, void* stream);
+/* Its backward through the activation, layout NN: C = (A.B) * gelu'(H)  (A = gradient of BertOutput.dense's output, B = its
+ * weight [K,N], H = the saved pre-activation [M,N], row stride ldc) plus part[t][n] = sum over the rows of row-tile t of the
+ * bf16 values stored in C: the partial rows of BertIntermediate's bias gradient (finish with kvq_reduce_batch over
+ * kvq_gemm_dgelu_partial_rows(M, tile) rows).  Replaces the dgrad GEMM + the elementwise gelu-backward + bias column sums. */
+int64_t kvq_gemm_dgelu_partial_rows(int64_t M, int tile);
+int kvq_gemm_bf16_dgelu(const void* A, const void* B, const void* H, void* C, float* part, size_t part_bytes, int M, int N, int K,
+                        int lda, int ldb, int ldc, int tile, void* stream);
 
 /* torch.optim.Adam step (models/shelgon3/main.py:91: lr, weight_decay (L2, coupled), amsgrad) on flat buffers.
  *   p, m, v [, vmax] f32; g grad_dtype (scaled by grad_scale first); shadow_bf16 (may be NULL) receives bf16(p_new).
@@ -351,12 +347,6 @@ int kvq_gumbel_forward(const void* logits, const float* noise, int64_t N, int K,
 int kvq_gumbel_backward(const void* logits, const float* y_soft, const void* g_y, const float* g_diff, int64_t N, int K, float tau,
                         float kld_scale, int io_dtype, void* g_logits, void* stream);
 
-
-/* Batched bf16 transposes, one launch: dst[i] [C][R] = src[i] [R][C]^T, i < n (device pointers in HOST arrays; not in place).
- * Keeps W^T beside the 768x768 projection weights so that their input-gradient GEMM g.W runs as the NT product of
- * kvq_gemm_nt_bf16 (refreshed once per optimiser step). */
-#define KVQ_TRANSPOSE_MAX 64
-int kvq_transpose_batch_bf16(const void* const* src, void* const* dst, int n, int R, int C, void* stream);
 
 #ifdef __cplusplus
 }

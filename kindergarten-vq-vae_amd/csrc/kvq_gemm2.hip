@@ -49,7 +49,26 @@ struct Problem {
     int tiles_m, tiles_n;
     int tile0;                         // first tile id of this problem in the launch
     int accumulate;                    // C += result
+    unsigned short* C2;                // EPI_GELU: second output gelu(C)
+    const unsigned short* H;           // EPI_DGELU: pre-activation h [M, N] (row stride ldc); C = (A.B) * gelu'(h)
+    float* part;                       // EPI_DGELU: [tiles_m][N] f32 column sums of C over each tile's rows (bias-gradient partials)
 };
+
+constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2;
+
+// erf to ~1.2e-7 absolute (Abramowitz & Stegun 7.1.26): far below bf16 output rounding, ~12 VALU ops
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_fast(float x) {
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
+    return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
 
 struct Params {
     Problem p[MAX_PROBLEMS];
@@ -68,7 +87,11 @@ struct Cfg {
     static constexpr int PIECES = (BM + BN) / 8;            // 1-KiB DMA pieces per k-tile
     static constexpr int PPW = PIECES / WAVES;              // per wave
     static constexpr int CLD = BN * 2 + 16;                 // epilogue row stride (bytes)
-    static constexpr int LDS = (NS * STAGE > BM * CLD) ? NS * STAGE : BM * CLD;
+    static constexpr int CPRP = 32;                         // epilogue: threads per tile row (>= BN / 8 chunks, power of two)
+    static constexpr int RPP = THREADS / CPRP;              // epilogue: tile rows per pass
+    static constexpr int EPI_BYTES = BM * CLD + RPP * BN * 4;   // bf16 tile + f32 column-sum scratch (EPI_DGELU)
+    static constexpr int LDS = (NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
+    static_assert(BN / 8 <= CPRP, "epilogue mapping");
     static_assert(PIECES % WAVES == 0, "DMA pieces must divide evenly over the waves");
     static_assert(TM % 16 == 0 && TN % 16 == 0 && BM % 64 == 0 && BN % 64 == 0, "tile shape");
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -199,25 +222,44 @@ __device__ __forceinline__ void read_frags(Frags<C>& f, const char* stage, int w
     for (int ni = 0; ni < C::FB; ++ni) f.b[ni] = read_frag<C::BKM>(stage + C::A_BYTES, wn * C::TN + ni * 16, ks, lane);
 }
 
-// One MFMA cluster (a k-step of the wave tile) with the DMA pieces [Q0, Q1) of the pending ring refill issued in between, evenly
-// spaced: a piece occupies the CU's address path for ~16-20 cycles, so 8 waves issuing their pieces back to back behind the
-// barrier stall each other for hundreds of cycles with the matrix pipe idle; one piece every few MFMAs never queues.
+// One MFMA cluster (a k-step of the wave tile) that also (a) reads the NEXT k-step's fragments from LDS and (b) issues the DMA
+// pieces [Q0, Q1) of the pending ring refill, both interleaved with the MFMAs:
+//   * a DMA piece occupies the CU's address path for ~16-20 cycles: 8 waves issuing theirs back to back behind the barrier stall
+//     each other for hundreds of cycles with the matrix pipe idle; one piece every few MFMAs never queues;
+//   * an LDS read issued between two MFMAs costs the matrix pipe nothing (MI355X_MICROARCH.md: <= 3 cycles per gap for two reads),
+//     a block of 16-20 reads in front of the cluster costs their issue time with the pipe empty.
+// The cluster is cut into NP + 1 sub-blocks by the pieces (pinned with sched_barrier); the reads go into the first sub-blocks so
+// that they have landed when the cluster ends; inside a sub-block the scheduler is asked for an MFMA / read alternation.
 template <class C, int Q0, int Q1>
-__device__ __forceinline__ void mma(f32x4 (&acc)[C::FA][C::FB], const Frags<C>& f, Stager<C>& sg, int slot, bool pending) {
-    constexpr int NM = C::FA * C::FB, NP = Q1 - Q0;
+__device__ __forceinline__ void mma(f32x4 (&acc)[C::FA][C::FB], const Frags<C>& f, Frags<C>& fn, const char* nstage, int nks,
+                                    int wm, int wn, int lane, Stager<C>& sg, int slot, bool pending) {
+    constexpr int NM = C::FA * C::FB, NP = Q1 - Q0, NSUB = NP + 1, NF = C::FA + C::FB;
+    constexpr int RSUB = NSUB > 1 ? NSUB - 1 : 1;                       // sub-blocks that carry reads
+    constexpr int RPF = (C::AK && C::BKM) ? 1 : 2;                      // upper bound of LDS instructions per fragment
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < NM; ++i) {
-        const int mi = i / C::FB, ni = i % C::FB;
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[ni], f.a[mi], acc[mi][ni], 0, 0, 0);
-        if constexpr (NP > 0) {
+    for (int sb = 0; sb < NSUB; ++sb) {
+        const int m0 = sb * NM / NSUB, m1 = (sb + 1) * NM / NSUB;
+        const int t0 = sb < RSUB ? sb * NF / RSUB : NF, t1 = sb < RSUB ? (sb + 1) * NF / RSUB : NF;
 #pragma unroll
-            for (int j = 0; j < NP; ++j)
-                if (i == (j + 1) * NM / (NP + 1) - 1) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (pending) sg.template piece_rt<Q0, Q1>(j, slot);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+        for (int t = t0; t < t1; ++t) {
+            if (t < C::FA) fn.a[t] = read_frag<C::AK>(nstage, wm * C::TM + t * 16, nks, lane);
+            else fn.b[t - C::FA] = read_frag<C::BKM>(nstage + C::A_BYTES, wn * C::TN + (t - C::FA) * 16, nks, lane);
+        }
+#pragma unroll
+        for (int i = m0; i < m1; ++i) {
+            const int mi = i / C::FB, ni = i % C::FB;
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[ni], f.a[mi], acc[mi][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = m0; i < m1; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // one MFMA
+            if (i - m0 < t1 - t0) __builtin_amdgcn_sched_group_barrier(0x100, RPF, 0);           // one fragment's LDS reads
+        }
+        if (sb + 1 < NSUB) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (pending) sg.template piece_rt<Q0, Q1>(sb, slot);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -228,7 +270,7 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class C>
+template <class C, int EPI>
 __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -267,8 +309,9 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
 
-    // ---- main loop: per k-tile  [f0 ready] read f1 | MFMA(f0) + 2nd half of the refill | f1 ready, tile kt+1 landed, barrier,
-    //                             read next f0 | MFMA(f1) + 1st half of the refill of the slot just freed
+    // ---- main loop: per k-tile
+    //   MFMA(f0) || read f1 || 2nd half of the pending refill  |  f1 ready, tile kt+1 landed, barrier  |
+    //   MFMA(f1) || read next f0 || 1st half of the refill of the slot just freed
     Frags<C> f0, f1;
     read_frags<C>(f0, smem, wm, wn, 0, lane);
     constexpr int PH = C::PPW / 2;                                         // pieces issued inside the first cluster after the barrier
@@ -276,30 +319,49 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
     bool pending = false;
     for (int kt = 0; kt < nkt; ++kt) {
         const char* st = smem + slot * C::STAGE;
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): f0 (issued a whole MFMA cluster ago)
-        read_frags<C>(f1, st, wm, wn, 1, lane);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): f0 (its reads ended half a cluster ago)
         __builtin_amdgcn_sched_barrier(0);
-        mma<C, PH, C::PPW>(acc, f0, sg, pslot, pending);
+        mma<C, PH, C::PPW>(acc, f0, f1, st, 1, wm, wn, lane, sg, pslot, pending);
         if (pending) sg.advance();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);                                // f1 arrived: this wave is done with `slot`
         pending = false;
-        if (kt + 1 < nkt) {
+        const bool more = kt + 1 < nkt;
+        const int nslot = slot + 1 == C::NS ? 0 : slot + 1;
+        if (more) {
             if (kt + C::NS <= nkt) wait_vm<(C::NS - 2) * C::PPW>();         // tiles kt+2 .. kt+NS-1 may still be in flight
             else wait_vm<0>();
             __builtin_amdgcn_s_barrier();                                  // tile kt+1 landed for everybody; `slot` is free
             pending = kt + C::NS < nkt;
             pslot = slot;
-            const int nslot = slot + 1 == C::NS ? 0 : slot + 1;
-            read_frags<C>(f0, smem + nslot * C::STAGE, wm, wn, 0, lane);
-            slot = nslot;
         }
         __builtin_amdgcn_sched_barrier(0);
-        mma<C, 0, PH>(acc, f1, sg, pslot, pending);
+        // (after the last k-tile this still reads a ring slot -- stale bytes, inside the ring, never used)
+        mma<C, 0, PH>(acc, f1, f0, smem + nslot * C::STAGE, 0, wm, wn, lane, sg, pslot, pending);
+        slot = nslot;
     }
     __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring becomes the epilogue tile
 
-    // ---- epilogue: acc -> (bias) -> bf16 tile in LDS -> whole row segments (+C) -> global
+    // ---- epilogue: acc -> (bias) -> bf16 tile in LDS -> whole row segments -> (+C | * gelu'(H)) -> global
+    // A thread owns ONE 16-byte column chunk of the tile and NIT rows (r = rr + it * RPP).  Whatever the row segments need from
+    // memory (the old C of an accumulate, the pre-activation H) is requested for all NIT rows up front, before the transposition
+    // through LDS: one round trip instead of NIT dependent ones.
+    constexpr int CPR = C::BN / 8;                                         // 16-byte chunks per tile row
+    constexpr int NIT = C::BM / C::RPP;
+    const int c16 = tid % C::CPRP, rr = tid / C::CPRP;
+    const int n = n0 + c16 * 8;
+    const bool colok = c16 < CPR && n < pr.N;                              // N % 8 == 0: a chunk is inside or outside as a whole
+    const bool accum = EPI == EPI_NONE && pr.accumulate != 0;
+    const unsigned short* auxp = EPI == EPI_DGELU ? pr.H : pr.C;
+    uint4 aux[NIT];
+    if (EPI == EPI_DGELU || accum) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int m = m0 + rr + it * C::RPP;
+            m = m < pr.M ? m : pr.M - 1;                                   // clamped; out-of-range rows are never stored
+            aux[it] = colok ? *reinterpret_cast<const uint4*>(auxp + (size_t)m * pr.ldc + n) : make_uint4(0, 0, 0, 0);
+        }
+    }
     // lane holds, for (mi, ni): row m = wm*TM + mi*16 + (lane & 15), columns n = wn*TN + ni*16 + 4*(lane >> 4) + 0..3
     const int frow = lane & 15, fk = lane >> 4;
 #pragma unroll
@@ -321,19 +383,17 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
         }
     }
     __syncthreads();
-    constexpr int CPR = C::BN / 8;                                         // 16-byte chunks per tile row
-    constexpr int CHUNKS = C::BM * CPR;
-#pragma unroll 4
-    for (int cid = tid; cid < CHUNKS; cid += C::THREADS) {
-        const int r = cid / CPR, c16 = cid - r * CPR;
-        const int m = m0 + r, n = n0 + c16 * 8;
-        if (m < pr.M && n < pr.N) {                                        // N % 8 == 0: a chunk is inside or outside as a whole
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int r = rr + it * C::RPP;
+        const int m = m0 + r;
+        if (colok && m < pr.M) {
             uint4 v = *reinterpret_cast<const uint4*>(smem + r * C::CLD + c16 * 16);
+            unsigned* vn = reinterpret_cast<unsigned*>(&v);
             const size_t off = (size_t)m * pr.ldc + n;
-            if (pr.accumulate) {
-                unsigned* vn = reinterpret_cast<unsigned*>(&v);
-                const uint4 old = *reinterpret_cast<const uint4*>(pr.C + off);
-                const unsigned* vo = reinterpret_cast<const unsigned*>(&old);
+            if (accum) {
+                const unsigned* vo = reinterpret_cast<const unsigned*>(&aux[it]);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float lo = __uint_as_float(vn[u] << 16) + __uint_as_float(vo[u] << 16);
@@ -341,7 +401,44 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
                     vn[u] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
                 }
             }
+            if (EPI == EPI_DGELU) {                                        // C = (A.B) * gelu'(h); column sums of what is stored
+                const unsigned* hv = reinterpret_cast<const unsigned*>(&aux[it]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned short lo = f32_to_bf16(__uint_as_float(vn[u] << 16) * dgelu_fast(__uint_as_float(hv[u] << 16)));
+                    const unsigned short hi = f32_to_bf16(__uint_as_float(vn[u] & 0xffff0000u) * dgelu_fast(__uint_as_float(hv[u] & 0xffff0000u)));
+                    cs[2 * u] += bf16_to_f32(lo);
+                    cs[2 * u + 1] += bf16_to_f32(hi);
+                    vn[u] = (unsigned)lo | ((unsigned)hi << 16);
+                }
+            }
             *reinterpret_cast<uint4*>(pr.C + off) = v;
+            if (EPI == EPI_GELU) {                                         // second output a = gelu(h), h = the bf16 value just stored
+                uint4 g;
+                unsigned* gv = reinterpret_cast<unsigned*>(&g);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float lo = gelu_fast(__uint_as_float(vn[u] << 16));
+                    const float hi = gelu_fast(__uint_as_float(vn[u] & 0xffff0000u));
+                    gv[u] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                }
+                *reinterpret_cast<uint4*>(pr.C2 + off) = g;
+            }
+        }
+    }
+    if (EPI == EPI_DGELU) {
+        // column sums over the tile's rows: RPP partial rows through LDS (behind the bf16 tile), then one thread per column
+        float* scratch = reinterpret_cast<float*>(smem + C::BM * C::CLD);
+        if (c16 < CPR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) scratch[rr * C::BN + c16 * 8 + j] = cs[j];
+        }
+        __syncthreads();
+        if (tid < C::BN && n0 + tid < pr.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < C::RPP; ++q) t += scratch[q * C::BN + tid];
+            pr.part[(size_t)tm * pr.N + n0 + tid] = t;
         }
     }
 }
@@ -353,15 +450,15 @@ template <bool AK, bool BKM> using Cfg256x192 = Cfg<256, 192, 4, 2, AK, BKM, 2>;
 template <bool AK, bool BKM> using Cfg128x192 = Cfg<128, 192, 2, 2, AK, BKM, 3>;     // 4 waves, 120 KiB: 256 tiles at N = 768
 template <bool AK, bool BKM> using Cfg256x256 = Cfg<256, 256, 2, 4, AK, BKM, 2>;     // 8 waves, 128 KiB
 
-template <class C>
+template <class C, int EPI = EPI_NONE>
 static int launch_cfg(const Params& P, hipStream_t st) {
     static bool attr_done = false;                 // per instantiation; idempotent, so a race only repeats the call
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<C, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm2): %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm2_kernel<C>, dim3((unsigned)P.ntiles), dim3(C::THREADS), C::LDS, st, P);
+    hipLaunchKernelGGL((gemm2_kernel<C, EPI>), dim3((unsigned)P.ntiles), dim3(C::THREADS), C::LDS, st, P);
     return check_launch("gemm2_kernel");
 }
 
@@ -389,37 +486,43 @@ static void tile_of(int tile, int& bm, int& bn) {
 
 using namespace kvq;
 
-extern "C" {
-
-int kvq_gemm_grouped_bf16(const kvq_gemm_problem* probs, int nprob, int layout, int tile, void* stream) {
-    KVQ_REQUIRE(probs && nprob >= 1 && nprob <= g2::MAX_PROBLEMS, "kvq_gemm_grouped_bf16: 1..%d problems per launch", g2::MAX_PROBLEMS);
-    KVQ_REQUIRE(layout == KVQ_GEMM_NT || layout == KVQ_GEMM_NN || layout == KVQ_GEMM_TN, "kvq_gemm_grouped_bf16: unknown layout %d", layout);
-    KVQ_REQUIRE(tile >= KVQ_GEMM_TILE_128x192 && tile <= KVQ_GEMM_TILE_256x256, "kvq_gemm_grouped_bf16: unknown tile %d", tile);
+static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, int tile, g2::Params& P, const char* who) {
+    KVQ_REQUIRE(probs && nprob >= 1 && nprob <= g2::MAX_PROBLEMS, "%s: 1..%d problems per launch", who, g2::MAX_PROBLEMS);
+    KVQ_REQUIRE(layout == KVQ_GEMM_NT || layout == KVQ_GEMM_NN || layout == KVQ_GEMM_TN, "%s: unknown layout %d", who, layout);
+    KVQ_REQUIRE(tile >= KVQ_GEMM_TILE_128x192 && tile <= KVQ_GEMM_TILE_256x256, "%s: unknown tile %d", who, tile);
     int bm, bn;
     g2::tile_of(tile, bm, bn);
-    g2::Params P;
     P.nprob = nprob;
     int t0 = 0;
     for (int i = 0; i < nprob; ++i) {
         const kvq_gemm_problem& q = probs[i];
-        KVQ_REQUIRE(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "kvq_gemm_grouped_bf16: problem %d: bad argument", i);
-        KVQ_REQUIRE(q.K % g2::BK == 0, "kvq_gemm_grouped_bf16: problem %d: K=%d must be a multiple of %d", i, q.K, g2::BK);
+        KVQ_REQUIRE(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "%s: problem %d: bad argument", who, i);
+        KVQ_REQUIRE(q.K % g2::BK == 0, "%s: problem %d: K=%d must be a multiple of %d", who, i, q.K, g2::BK);
         KVQ_REQUIRE(q.M % 8 == 0 && q.N % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc % 8 == 0 && q.M >= 8 && q.N >= 8,
-                    "kvq_gemm_grouped_bf16: problem %d: M, N, lda, ldb, ldc must be multiples of 8", i);
+                    "%s: problem %d: M, N, lda, ldb, ldc must be multiples of 8", who, i);
         KVQ_REQUIRE((((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15) == 0 && (!q.bias || ((uintptr_t)q.bias & 7) == 0),
-                    "kvq_gemm_grouped_bf16: problem %d: operands must be 16-byte aligned", i);
+                    "%s: problem %d: operands must be 16-byte aligned", who, i);
         // leading dimensions must cover the rows the kernel reads
         const int a_cols = layout == KVQ_GEMM_TN ? q.M : q.K, b_cols = layout == KVQ_GEMM_NT ? q.K : q.N;
-        KVQ_REQUIRE(q.lda >= a_cols && q.ldb >= b_cols && q.ldc >= q.N, "kvq_gemm_grouped_bf16: problem %d: leading dimension too small", i);
+        KVQ_REQUIRE(q.lda >= a_cols && q.ldb >= b_cols && q.ldc >= q.N, "%s: problem %d: leading dimension too small", who, i);
         g2::Problem& d = P.p[i];
         d.A = (const unsigned short*)q.A; d.B = (const unsigned short*)q.B; d.C = (unsigned short*)q.C; d.bias = (const unsigned short*)q.bias;
         d.M = q.M; d.N = q.N; d.K = q.K; d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc;
         d.tiles_m = (q.M + bm - 1) / bm; d.tiles_n = (q.N + bn - 1) / bn;
         d.tile0 = t0; d.accumulate = q.accumulate;
+        d.C2 = nullptr; d.H = nullptr; d.part = nullptr;
         t0 += d.tiles_m * d.tiles_n;
     }
     for (int i = nprob; i < g2::MAX_PROBLEMS; ++i) P.p[i] = P.p[0];
     P.ntiles = t0;
+    return KVQ_OK;
+}
+
+extern "C" {
+
+int kvq_gemm_grouped_bf16(const kvq_gemm_problem* probs, int nprob, int layout, int tile, void* stream) {
+    g2::Params P;
+    if (int rc = build_params(probs, nprob, layout, tile, P, "kvq_gemm_grouped_bf16")) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (tile) {
         case KVQ_GEMM_TILE_128x256: return g2::launch_layout<g2::Cfg128x256>(layout, P, st);
@@ -434,6 +537,41 @@ int kvq_gemm_bf16(const void* A, const void* B, const void* bias, void* C, int M
     kvq_gemm_problem q;
     q.A = A; q.B = B; q.C = C; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.accumulate = accumulate;
     return kvq_gemm_grouped_bf16(&q, 1, layout, tile, stream);
+}
+
+int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hout, void* Aout, int M, int N, int K, int lda, int ldb,
+                       int ldc, int tile, void* stream) {
+    KVQ_REQUIRE(Aout && ((uintptr_t)Aout & 15) == 0, "kvq_gemm_bf16_gelu: null / misaligned second output");
+    KVQ_REQUIRE(tile == KVQ_GEMM_TILE_256x192 || tile == KVQ_GEMM_TILE_128x256, "kvq_gemm_bf16_gelu: tile must be 256x192 or 128x256");
+    kvq_gemm_problem q;
+    q.A = A; q.B = B; q.C = Hout; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.accumulate = 0;
+    g2::Params P;
+    if (int rc = build_params(&q, 1, KVQ_GEMM_NT, tile, P, "kvq_gemm_bf16_gelu")) return rc;
+    for (int i = 0; i < g2::MAX_PROBLEMS; ++i) P.p[i].C2 = (unsigned short*)Aout;
+    hipStream_t st = (hipStream_t)stream;
+    if (tile == KVQ_GEMM_TILE_256x192) return g2::launch_cfg<g2::Cfg256x192<true, true>, g2::EPI_GELU>(P, st);
+    return g2::launch_cfg<g2::Cfg128x256<true, true>, g2::EPI_GELU>(P, st);
+}
+
+int64_t kvq_gemm_dgelu_partial_rows(int64_t M, int tile) {
+    int bm, bn;
+    g2::tile_of(tile, bm, bn);
+    return (M + bm - 1) / bm;
+}
+
+int kvq_gemm_bf16_dgelu(const void* A, const void* B, const void* H, void* C, float* part, size_t part_bytes, int M, int N, int K,
+                        int lda, int ldb, int ldc, int tile, void* stream) {
+    KVQ_REQUIRE(H && part && ((uintptr_t)H & 15) == 0, "kvq_gemm_bf16_dgelu: null / misaligned pre-activation or partial buffer");
+    KVQ_REQUIRE(tile == KVQ_GEMM_TILE_256x192 || tile == KVQ_GEMM_TILE_128x256, "kvq_gemm_bf16_dgelu: tile must be 256x192 or 128x256");
+    KVQ_REQUIRE(part_bytes >= (size_t)kvq_gemm_dgelu_partial_rows(M, tile) * N * sizeof(float), "kvq_gemm_bf16_dgelu: partial buffer too small");
+    kvq_gemm_problem q;
+    q.A = A; q.B = B; q.C = C; q.bias = nullptr; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.accumulate = 0;
+    g2::Params P;
+    if (int rc = build_params(&q, 1, KVQ_GEMM_NN, tile, P, "kvq_gemm_bf16_dgelu")) return rc;
+    for (int i = 0; i < g2::MAX_PROBLEMS; ++i) { P.p[i].H = (const unsigned short*)H; P.p[i].part = part; }
+    hipStream_t st = (hipStream_t)stream;
+    if (tile == KVQ_GEMM_TILE_256x192) return g2::launch_cfg<g2::Cfg256x192<true, false>, g2::EPI_DGELU>(P, st);
+    return g2::launch_cfg<g2::Cfg128x256<true, false>, g2::EPI_DGELU>(P, st);
 }
 
 }  // extern "C"

@@ -78,13 +78,11 @@ SIGNATURES = {
                             C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp]),
     "kvq_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32,
                             C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
-    "kvq_gemm_nt_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
-    "kvq_gemm_set_stages": (_int, [_int]),
     "kvq_gemm_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_grouped_bf16": (_int, [C.POINTER(GemmProblem), _int, _int, _int, _vp]),
-    "kvq_transpose_batch_bf16": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int, _int, _int, _vp]),
-    "kvq_gemm_nt_bf16_gelu": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
-    "kvq_gemm_nt_bf16_dgelu": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "kvq_gemm_bf16_gelu": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "kvq_gemm_dgelu_partial_rows": (_i64, [_i64, _int]),
+    "kvq_gemm_bf16_dgelu": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_attn_set_variant": (_int, [_int]),
     "kvq_adam_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "kvq_step_state_advance": (_int, [_vp, _f32, _f32, C.POINTER(_i64), _int, _f32, _f32, _vp]),

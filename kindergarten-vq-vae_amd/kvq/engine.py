@@ -244,6 +244,11 @@ class TrainEngine:
         self._step_seed = (self.seed * 1000003) & 0x7FFFFFFFFFFFFFF      # + step count on the device
         self._graphs, self._eager_seen, self._cap = {}, {}, None
         self._own_fwd = os.environ.get("KVQ_OWN_GEMM", "1") != "0"
+        for attr, var in (("_OWN_FWD", "KVQ_OWN_FWD"), ("_OWN_DGRAD", "KVQ_OWN_DGRAD"), ("_OWN_GELU", "KVQ_OWN_GELU"),
+                          ("_OWN_DGELU", "KVQ_OWN_DGELU"), ("_OWN_WGRAD_SINGLE", "KVQ_OWN_WGRAD_SINGLE")):
+            if var in os.environ:       # "NxK:tile;NxK:tile" replaces the table (A/B runs on the GPU box); "" = all library
+                setattr(self, attr, {tuple(int(v) for v in e.split(":")[0].split("x")): e.split(":")[1]
+                                     for e in os.environ[var].split(";") if e})
         # weight gradients of a whole layer as ONE grouped launch of csrc/kvq_gemm2.hip (KVQ_OWN_WGRAD=0: library + split-K slabs)
         self._own_wgrad = self._own_fwd and os.environ.get("KVQ_OWN_WGRAD", "1") != "0" and self.dtype == torch.bfloat16
         self._wg_items, self._wg_keep = [], []
@@ -374,7 +379,15 @@ class TrainEngine:
     # (N, K) -> workgroup tile of csrc/kvq_gemm2.hip for the shapes where it beats the tuned library at 8192 rows
     # (tools/gemm2_probe.py on MI355X, interleaved rounds; gpurun_out/g2_probe*.log); every other shape stays with hipBLASLt
     _OWN_FWD = {(768, 768): "128x256"}                                          # y = x . W^T + b        ("nt")
-    _OWN_DGRAD = {(768, 768): "128x256", (768, 3072): "128x256", (3072, 768): "256x192", (768, 18432): "128x256"}   # gx = gy . W ("nn")
+    _OWN_DGRAD = {(768, 768): "128x256", (768, 2304): "128x256", (768, 3072): "128x256", (3072, 768): "256x192",
+                  (768, 18432): "128x256"}                                      # gx = gy . W            ("nn")
+    # BertIntermediate / its backward with the activation inside the GEMM epilogue: (N, K) -> tile
+    # Measured on MI355X (tools/gemm2_probe.py epi): the fused kernels TIE with GEMM + separate activation kernel (FFN1 forward
+    # 66.1 vs 47.5 + 19.3 us, FFN2 backward 79.5 vs 47.1 + 29.8 us) -- the exact-erf VALU work (two transcendentals per
+    # element) runs behind the MFMA loop of a one-workgroup-per-CU kernel instead of beside it -- so they stay opt-in
+    # (KVQ_OWN_GELU / KVQ_OWN_DGELU = "3072x768:256x192").
+    _OWN_GELU = {}                                                              # (h, gelu(h)) = x . W^T + b
+    _OWN_DGELU = {}                                                             # (gy . W) * gelu'(h) + bias-gradient partials
     _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "256x192"}      # gW = gy^T . x          ("tn"), own launch
 
     def _linear(self, x, wname, bname, fused=None):
@@ -385,6 +398,15 @@ class TrainEngine:
             if tile is not None:
                 return nnops.gemm(x, W, "nt", bias=b, tile=tile)
         return torch.addmm(b, x, W.t())
+
+    def _linear_gelu(self, x, wname, bname):
+        """(h, gelu(h)), h = x . W^T + b: one kernel where the own GEMM carries the activation in its epilogue."""
+        W, b = self.flat.w(wname), self.flat.w(bname)
+        tile = self._OWN_GELU.get(tuple(W.shape)) if self._own_fwd and self.dtype == torch.bfloat16 and x.shape[0] >= 2048 else None
+        if tile is not None and x.is_contiguous():
+            return nnops.gemm_gelu(x, W, b, tile=tile)
+        h = self._linear(x, wname, bname)
+        return h, nnops.gelu_fwd(h)
 
     # split-K factors for the weight-gradient GEMMs gW[M,N] = gy[Ntok,M]^T x[Ntok,N]: the contraction (Ntok = 8192) is long
     # and the output small, so a single GEMM leaves most CUs idle; S batched slices + one sum fill the chip
@@ -624,8 +646,7 @@ class TrainEngine:
         fl = self.flat
         p_hid = cfg.hidden_dropout_prob if training else 0.0
         site = self._site()
-        h = self._linear(x, pre + "f1.w", pre + "f1.b")
-        a = nnops.gelu_fwd(h)
+        h, a = self._linear_gelu(x, pre + "f1.w", pre + "f1.b")
         f = self._linear(a, pre + "f2.w", pre + "f2.b")
         out, lnpre, mean, rstd = nnops.ln_fwd(f, x, fl.w32(pre + "ln2.w"), fl.w32(pre + "ln2.b"), cfg.layer_norm_eps,
                                               p_hid, self._step_seed, site)
@@ -639,6 +660,16 @@ class TrainEngine:
                                 g_gamma=fl.g(pre + "ln2.w") if tr[pre + "ln2.w"] else None,
                                 g_beta=fl.g(pre + "ln2.b") if tr[pre + "ln2.b"] else None,
                                 g_bias_prev=fl.g(pre + "f2.b") if tr[pre + "f2.b"] else None)
+        W2 = fl.w(pre + "f2.w")
+        tile = self._OWN_DGELU.get((W2.shape[1], W2.shape[0])) if self._own_fwd and self.dtype == torch.bfloat16 else None
+        if tile is not None and g_f.shape[0] >= 2048 and g_f.is_contiguous() and h.is_contiguous():
+            # input gradient of f2, the activation's derivative and the f1-bias partial sums in ONE kernel
+            self._linear_bwd(g_f, a, [pre + "f2.w"], [pre + "f2.b"], need_gx=False, bias_done=True)      # queues the f2 weight gradient
+            g_h, pb = nnops.gemm_dgelu(g_f, W2, h, tile=tile)
+            if tr[pre + "f1.b"]:
+                self._defer(pb, fl.g(pre + "f1.b"), pb.shape[0], pb.shape[1], pb.shape[1])
+            self._linear_bwd(g_h, x, [pre + "f1.w"], [pre + "f1.b"], gx_accum=g_x, bias_done=True)
+            return g_x
         g_a = self._linear_bwd(g_f, a, [pre + "f2.w"], [pre + "f2.b"], bias_done=True)
         if tr[pre + "f1.b"] and h.is_contiguous() and h.shape[1] % 8 == 0:
             g_h, pb = nnops.gelu_bwd_bias(h, g_a, out=g_a)           # bias gradient partials come out of the same pass
@@ -796,8 +827,7 @@ class TrainEngine:
                                          kv_pre=kv_all[:, 2 * H * i: 2 * H * (i + 1)] if kv_all is not None else None)
             y, ff = self._ffn_fwd(f"dec.{i}.", y, dcfg, training)
             dec_saved.append((sa, ca, ff))
-        t = self._linear(y, "head.t.w", "head.t.b")
-        ta = nnops.gelu_fwd(t)
+        t, ta = self._linear_gelu(y, "head.t.w", "head.t.b")
         hN, hpre, hmean, hrstd = nnops.ln_fwd(ta, None, fl.w32("head.ln.w"), fl.w32("head.ln.b"), dcfg.layer_norm_eps)
         Wv = fl.w("dec.emb.word", rows=self.Vp)                              # [Vp,H], rows >= V are zero
         bv = fl.shadow[fl.seg["head.bias"][0]: fl.seg["head.bias"][0] + self.Vp]

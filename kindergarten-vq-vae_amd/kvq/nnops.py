@@ -219,59 +219,6 @@ def embed_grad(g, perm, sorted_ids, gW, accumulate=False):
     return gW
 
 
-class TransposeBatch:
-    """dst[i] = src[i].T for lists of same-shaped contiguous bf16 matrices, one launch (pointer tables built once)."""
-
-    def __init__(self, srcs, dsts):
-        import ctypes
-        assert len(srcs) == len(dsts) and len(srcs) >= 1
-        self.R, self.C = srcs[0].shape
-        for a, b in zip(srcs, dsts):
-            require_gpu(a, b)
-            assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.is_contiguous() and b.is_contiguous()
-            assert tuple(a.shape) == (self.R, self.C) and tuple(b.shape) == (self.C, self.R)
-        self.n = len(srcs)
-        self._keep = (list(srcs), list(dsts))
-        self._src = (ctypes.c_void_p * self.n)(*[a.data_ptr() for a in srcs])
-        self._dst = (ctypes.c_void_p * self.n)(*[b.data_ptr() for b in dsts])
-
-    def run(self):
-        check(lib().kvq_transpose_batch_bf16(self._src, self._dst, self.n, self.R, self.C, stream_ptr()), "kvq_transpose_batch_bf16")
-
-
-def gemm_nt(a, b, bias=None, out=None, accumulate=False):
-    """out[M,N] (= | +=) a[M,K] @ b[N,K].T (+ bias), bf16, hand-written MFMA kernel (csrc/kvq_gemm.hip)."""
-    require_gpu(a, b)
-    M, K = a.shape
-    N = b.shape[0]
-    if out is None:
-        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    check(lib().kvq_gemm_nt_bf16(a.data_ptr(), b.data_ptr(), _p(bias), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
-                                 out.stride(0), int(accumulate), stream_ptr()), "kvq_gemm_nt_bf16")
-    return out
-
-
-def gemm_nt_gelu(a, b, bias):
-    """(h, gelu(h)) with h = a @ b.T + bias in one kernel (BertIntermediate)."""
-    M, K = a.shape
-    N = b.shape[0]
-    h = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    g = torch.empty_like(h)
-    check(lib().kvq_gemm_nt_bf16_gelu(a.data_ptr(), b.data_ptr(), _p(bias), h.data_ptr(), g.data_ptr(), M, N, K, a.stride(0),
-                                      b.stride(0), h.stride(0), stream_ptr()), "kvq_gemm_nt_bf16_gelu")
-    return h, g
-
-
-def gemm_nt_dgelu(a, b, h):
-    """(a @ b.T) * gelu'(h) in one kernel (input gradient of BertOutput.dense pushed through the activation)."""
-    M, K = a.shape
-    N = b.shape[0]
-    out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    check(lib().kvq_gemm_nt_bf16_dgelu(a.data_ptr(), b.data_ptr(), h.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
-                                       out.stride(0), stream_ptr()), "kvq_gemm_nt_bf16_dgelu")
-    return out
-
-
 # ---- the GEMM family of csrc/kvq_gemm2.hip ---------------------------------------------------------------------------------
 _LAYOUTS = {"nt": 0, "nn": 1, "tn": 2}
 TILES = {"128x192": 0, "128x256": 1, "256x192": 2, "256x256": 3}
@@ -330,3 +277,29 @@ def gemm_grouped(problems, layout, tile):
     arr = (GemmProblem * len(problems))(*problems)
     t = TILES[tile] if isinstance(tile, str) else tile
     check(lib().kvq_gemm_grouped_bf16(arr, len(problems), _LAYOUTS[layout], t, stream_ptr()), "kvq_gemm_grouped_bf16")
+
+
+def gemm_gelu(x, w, bias, tile="256x192"):
+    """(h, gelu(h)) with h = x @ w.T + bias in one kernel (BertIntermediate, modeling_bert.py:325-337)."""
+    M, K = x.shape
+    N = w.shape[0]
+    h = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    a = torch.empty_like(h)
+    check(lib().kvq_gemm_bf16_gelu(x.data_ptr(), w.data_ptr(), _p(bias), h.data_ptr(), a.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+                                   h.stride(0), TILES[tile], stream_ptr()), "kvq_gemm_bf16_gelu")
+    return h, a
+
+
+def gemm_dgelu(gy, w, h, tile="256x192"):
+    """(g_h, part): g_h = (gy @ w) * gelu'(h) and part [rows, N] f32 partial column sums of g_h (bias-gradient partials for
+    reduce_batch()) in one kernel -- the input gradient of BertOutput.dense pushed through BertIntermediate's activation."""
+    M, K = gy.shape
+    N = w.shape[1]
+    assert tuple(h.shape) == (M, N) and h.is_contiguous()
+    out = torch.empty((M, N), dtype=gy.dtype, device=gy.device)
+    l = lib()
+    t = TILES[tile]
+    part = torch.empty((l.kvq_gemm_dgelu_partial_rows(M, t), N), dtype=torch.float32, device=gy.device)
+    check(l.kvq_gemm_bf16_dgelu(gy.data_ptr(), w.data_ptr(), h.data_ptr(), out.data_ptr(), part.data_ptr(), part.numel() * 4, M, N, K,
+                                gy.stride(0), w.stride(0), out.stride(0), t, stream_ptr()), "kvq_gemm_bf16_dgelu")
+    return out, part

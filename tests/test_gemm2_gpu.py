@@ -99,3 +99,40 @@ def test_gemm_rejects_bad_arguments():
     b = torch.zeros((64, 100), device="cuda", dtype=torch.bfloat16)
     with pytest.raises(KvqError):
         nnops.gemm(a, b, "nt")                      # K = 100 is not a multiple of 64
+
+
+def _gelu(x):
+    return torch.nn.functional.gelu(x)
+
+
+@pytest.mark.parametrize("tile", ["256x192", "128x256"])
+def test_gemm_gelu_epilogue(tile):
+    """BertIntermediate (modeling_bert.py:325-337): h = x W^T + b and gelu(h) from one kernel."""
+    from kvq import nnops
+    M, N, K = 1032, 776, 256
+    a, b, ref = _ops("nt", M, N, K, seed=3)
+    bias = torch.randn(N, device="cuda").to(torch.bfloat16)
+    h, g = nnops.gemm_gelu(a, b, bias, tile=tile)
+    want_h = ref + bias.float()
+    _check(h, want_h, K)
+    want_g = _gelu(h.float())                                   # the activation of the bf16 value that was stored
+    assert (g.float() - want_g).abs().max().item() <= 2.0 ** -8 * want_g.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("tile", ["256x192", "128x256"])
+def test_gemm_dgelu_epilogue_and_bias_partials(tile):
+    """Autograd of BertOutput.dense + BertIntermediate's activation: g_h = (g W2) * gelu'(h); partial rows sum to colsum(g_h)."""
+    from kvq import nnops
+    M, N, K = 1032, 776, 256
+    gy, w, ref = _ops("nn", M, N, K, seed=4)
+    h = torch.randn((M, N), device="cuda").to(torch.bfloat16)
+    g_h, part = nnops.gemm_dgelu(gy, w, h, tile=tile)
+    hf = h.float().requires_grad_(True)
+    _gelu(hf).backward(ref.to(torch.bfloat16).float())          # the kernel rounds the product to bf16 before the derivative
+    want = hf.grad
+    assert (g_h.float() - want).abs().max().item() <= 2.0 ** -7 * want.abs().max().item() + 1e-3
+    bm = int(tile.split("x")[0])
+    assert part.shape == (-(-M // bm), N)
+    torch.testing.assert_close(part.sum(0), g_h.float().sum(0), rtol=1e-4, atol=1e-2)
+    for t in range(part.shape[0]):                                # each partial row is exactly its row tile's column sum
+        torch.testing.assert_close(part[t], g_h[t * bm:(t + 1) * bm].float().sum(0), rtol=1e-4, atol=1e-3)

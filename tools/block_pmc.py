@@ -13,6 +13,6 @@ for _ in range(6):
     nnops.attn_fwd(qkv[:, :H], qkv[:, H:2*H], qkv[:, 2*H:], mask, B, nh, S, S, True, 0.1, 1, 2)
     nnops.attn_bwd(qkv[:, :H], qkv[:, H:2*H], qkv[:, 2*H:], mask, g, B, nh, S, S, True, 0.1, 1, 2, gq[:, :H], gq[:, H:2*H], gq[:, 2*H:],
                    pb[:, :H], pb[:, H:2*H], pb[:, 2*H:])
-    nnops.gemm_nt(a, w, bias, out=out)
+    nnops.gemm(a, w, "nt", bias=bias, out=out)
 torch.cuda.synchronize()
 print("ok")

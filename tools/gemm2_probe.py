@@ -87,3 +87,29 @@ if which in ("wgrad", "all"):
         print(f"enc-layer wgrad grouped {tile}: {ts[len(ts)//2]:7.1f} us {fl / ts[len(ts)//2] / 1e6:6.0f} TF", flush=True)
     ts = sorted(bench(lib4) for _ in range(rounds))
     print(f"enc-layer wgrad 4 x torch.mm: {ts[len(ts)//2]:7.1f} us {fl / ts[len(ts)//2] / 1e6:6.0f} TF", flush=True)
+if which in ("epi", "all"):
+    # epilogue variants at the FFN shapes: accumulate, GELU, dGELU + bias partials
+    x, w1, b1 = rnd(T, 768), rnd(3072, 768), rnd(3072)
+    h = torch.addmm(b1, x, w1.t())
+    gf, w2 = rnd(T, 768), rnd(768, 3072)
+    gx = rnd(T, 768)
+    gy3 = rnd(T, 3072)
+    w1n = rnd(3072, 768)
+    cases = {
+        "FFN1 fwd lib addmm+gelu": lambda: torch.nn.functional.gelu(torch.addmm(b1, x, w1.t())),
+        "FFN1 fwd own plain 256x192": lambda: nnops.gemm(x, w1, "nt", bias=b1, tile="256x192"),
+        "FFN1 fwd own fused gelu 256x192": lambda: nnops.gemm_gelu(x, w1, b1, tile="256x192"),
+        "FFN1 fwd own fused gelu 128x256": lambda: nnops.gemm_gelu(x, w1, b1, tile="128x256"),
+        "FFN2 dgrad own plain 256x192": lambda: nnops.gemm(gf, w2, "nn", tile="256x192"),
+        "FFN2 dgrad own fused dgelu 256x192": lambda: nnops.gemm_dgelu(gf, w2, h, tile="256x192"),
+        "FFN2 dgrad own fused dgelu 128x256": lambda: nnops.gemm_dgelu(gf, w2, h, tile="128x256"),
+        "FFN1 dgrad own 128x256": lambda: nnops.gemm(gy3, w1n, "nn", tile="128x256"),
+        "FFN1 dgrad own 128x256 accumulate": lambda: nnops.gemm(gy3, w1n, "nn", out=gx, accumulate=True, tile="128x256"),
+        "FFN1 dgrad lib addmm_": lambda: gx.addmm_(gy3, w1n),
+    }
+    res = {k: [] for k in cases}
+    for _ in range(rounds):
+        for k, f in cases.items():
+            res[k].append(bench(f))
+    for k, v in res.items():
+        print(f"{k:40s} {sorted(v)[len(v)//2]:7.1f} us", flush=True)
