@@ -2,7 +2,7 @@
 
 DS_GEN_SEED = 69                      # dataset split generator seed (consts.py:3)
 
-SUPPORTED_VQ_MODES = ["VectorQuantizer", "GumbelQuantizer"]
+SUPPORTED_VQ_MODES = ["VectorQuantizer", "GumbelQuantizer", "MultiVectorQuantizer"]
 
 RUN_ID_TIMESTAMP_FORMAT = "%Y_%m_%d_%H_%M_%S"
 RUNS_BASE_DIR = "./runs"

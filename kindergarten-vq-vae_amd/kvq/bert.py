@@ -1,17 +1,21 @@
-"""Forward of the BERT encoder / cross-attending BERT decoder used by Bagon and Shelgon, written against the
-PARAMETERS of HuggingFace's BertModel / BertLMHeadModel (so state dicts, init and checkpoints stay those of the
-reference: models/bagon/Bagon.py:24-31) but with its own execution plan for MI355X:
+"""ATen restatement of the BERT encoder / cross-attending BERT decoder used by Bagon and Shelgon -- the AUTOGRAD path.
+
+Plain torch ops (F.linear, F.scaled_dot_product_attention, F.layer_norm, F.gelu, F.dropout) over the PARAMETERS of HuggingFace's
+BertModel / BertLMHeadModel (so state dicts, init and checkpoints stay those of the reference: models/bagon/Bagon.py:24-31).
+This is NOT the product's execution plan: the hand-written HIP schedule lives in kvq/engine.py (training steps, and every
+Bagon / Shelgon.forward call made without autograd).  This file is what runs when torch autograd must differentiate the model
+(USE_ENGINE = False, sequences longer than 32 tokens, head widths other than 64) and it is the checker the engine's
+gradients are compared with in tests/test_engine_gpu.py.  Differences from HF's module-by-module forward:
 
   * one fused QKV projection per self-attention ([768 -> 2304] GEMM instead of three), one fused KV projection per
-    cross-attention, bf16 operands with f32 accumulation on the matrix cores;
-  * attention on S<=32-token sentences as one batched call per layer;
+    cross-attention, bf16 operands with f32 accumulation;
   * the LM head stops at the 768-d transform: the caller feeds `lm_head_logits` + the fused loss kernel
     (kvq_ce_forward) so the [N,V] log-softmax / one-hot tensors of the reference are never materialised.
 
 Math restated from transformers/models/bert/modeling_bert.py (v5.15): embeddings :53-108, self/cross attention
 :139-280, BertSelfOutput :282-293, BertIntermediate/BertOutput :325-352, BertLayer :354-417, LM head :466-497,
 mask construction :688-716.  HF's own forward is the third-party part of the reference; tests use it as the
-oracle for this file (tests/test_bert_parity.py).
+oracle for this file (tests/test_abi_and_host.py::test_bert_plan_equals_huggingface_forward).
 """
 from __future__ import annotations
 

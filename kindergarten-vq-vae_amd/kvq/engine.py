@@ -35,6 +35,21 @@ from .functional import _workspace
 
 V_ALIGN = 64   # vocabulary rows of the LM head are padded so logits rows are 128-byte aligned
 
+import weakref
+
+_ENGINES = weakref.WeakKeyDictionary()      # model -> the engine that owns its flat buffers (Bagon / Shelgon.forward reuse it)
+_QUANTIZERS = ("VectorQuantizer", "MultiVectorQuantizer", "GumbelQuantizer")
+
+
+def engine_of(model, create=True):
+    """The TrainEngine of `model` (its parameters live in that engine's flat buffers), created on first use."""
+    eng = _ENGINES.get(model)
+    if eng is not None and eng.flat.master.device != next(model.parameters()).device:
+        eng = None                                         # the model was moved after the engine was built
+    if eng is None and create:
+        eng = TrainEngine(model)
+    return eng
+
 
 def _round_up(x, a):
     return (x + a - 1) // a * a
@@ -159,7 +174,7 @@ class _StepGraphs:
         self.ids, self.mask = ids.clone(), mask.contiguous().clone()
         N, H = ids.numel(), eng.H
         self.z_q = torch.empty((N, H), dtype=eng.dtype, device=dev)
-        self.idx = torch.empty(N, dtype=torch.int64, device=dev)
+        self.idx = torch.empty(N * max(eng.G, 1), dtype=torch.int64, device=dev)
         self.vq_out = torch.empty(2, dtype=torch.float32, device=dev)
         self.graphs, self.inter = [torch.cuda.CUDAGraph()], []
         side = torch.cuda.Stream(device=dev)
@@ -221,9 +236,10 @@ class TrainEngine:
         self.dtype = model.compute_dtype
         self.io = 1 if self.dtype == torch.bfloat16 else 0
         self.has_vq = hasattr(model, "vector_quantizer")
-        if self.has_vq and type(model.vector_quantizer).__name__ != "VectorQuantizer":
-            raise KvqError(f"TrainEngine schedules the VectorQuantizer step; {type(model.vector_quantizer).__name__} models train "
-                           f"through Shelgon.forward_loss + torch autograd (USE_ENGINE = False)")
+        self.vq_kind = type(model.vector_quantizer).__name__ if self.has_vq else None
+        if self.has_vq and self.vq_kind not in _QUANTIZERS:
+            raise KvqError(f"TrainEngine schedules {', '.join(_QUANTIZERS)}; got {self.vq_kind}")
+        self.G = 1
         enc, dec = model.encoder, model.decoder
         self.ecfg, self.dcfg = enc.config, dec.config
         if self.ecfg.hidden_size // self.ecfg.num_attention_heads != 64:
@@ -334,13 +350,34 @@ class TrainEngine:
         self.nh = self.ecfg.num_attention_heads
         flags = {self.flat.trainable[n] for n in self._cakv_w + self._cakv_b}
         self._cakv_batched = len(flags) == 1 and self.n_dec_layers > 0       # mixed frozen / trained layers: per-layer GEMMs
-        if self.has_vq:
+        # small f32 parameters outside the flat buffers (codebook, Gumbel projection / embedding): own gradient + Adam state
+        self.aux = []
+        self._bufs = {}
+
+        def add_aux(p):
+            a = dict(p=p, g=torch.zeros_like(p.data), m=torch.zeros_like(p.data), v=torch.zeros_like(p.data),
+                     vmax=torch.zeros_like(p.data) if amsgrad else None)
+            self.aux.append(a)
+            return a["g"]
+
+        self.vq_ema = False
+        if self.vq_kind in ("VectorQuantizer", "MultiVectorQuantizer"):
             vq = model.vector_quantizer
-            self.E = vq.embedding.weight                      # f32 parameter, own tiny Adam state (f32 gradient)
-            self.gE = torch.zeros_like(self.E.data)
-            self.mE = torch.zeros_like(self.E.data); self.vE = torch.zeros_like(self.E.data)
-            self.vmaxE = torch.zeros_like(self.E.data) if amsgrad else None
+            self.G = int(getattr(vq, "n_factors", 1))         # codebooks = slices of the encoder output, one grouped launch
+            self.K, self.Dg = int(vq.n_e), self.H // self.G
+            self.E = vq.embedding.weight                      # f32 [G*K, H/G]
+            if self.E.shape != (self.G * self.K, self.Dg):
+                raise KvqError(f"TrainEngine: codebook {tuple(self.E.shape)} does not match {self.G} x {self.K} x {self.Dg}")
             self.beta_vq = float(vq.beta)
+            self.vq_ema = getattr(vq, "ema_decay", None) is not None     # extension: EMA codebook update instead of the gradient
+            self.gE = add_aux(self.E) if self.E.requires_grad else torch.zeros_like(self.E.data)
+        elif self.vq_kind == "GumbelQuantizer":
+            gq = model.vector_quantizer
+            if gq.n_embed > 1024:
+                raise KvqError("TrainEngine: the Gumbel row kernel holds at most 1024 codes")
+            self.g_pw, self.g_pb, self.g_emb = add_aux(gq.proj.weight), add_aux(gq.proj.bias), add_aux(gq.embed.weight)
+        _ENGINES[model] = self
+        self._param_versions = self._versions()
         # gradient all-reduce chunks (tail first)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
         self._avg_in_comm = self.world > 1 and dist.get_backend(process_group) == "nccl"   # RCCL averages itself; gloo sums
@@ -734,8 +771,9 @@ class TrainEngine:
         self._ev_early.record(self.comm_stream)
         if cut > 0:
             self._all_reduce_avg(self.flat.grad[:cut], late=True)
-        if self.has_vq:
-            self._all_reduce_avg(self.gE, late=True)
+        for a in self.aux:
+            if a["p"].requires_grad:
+                self._all_reduce_avg(a["g"], late=True)
         self._timed_wait(lambda main: main.wait_event(self._ev_early))
 
     def _exchange_tail(self):
@@ -768,31 +806,47 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------------------------
     # one training step
     # ------------------------------------------------------------------------------------------------------------
-    def forward_backward(self, input_ids, attention_mask, training=True, compute_grads=True):
-        """Forward (+ backward when compute_grads).  Returns dict(loss_recon, loss_vq, perplexity, acc, recon_ids, indices)."""
-        m = self.model
-        fl, H = self.flat, self.H
-        B, S = input_ids.shape
-        N = B * S
+    def forward_backward(self, input_ids, attention_mask, training=True, compute_grads=True, dec_ids=None, dec_mask=None,
+                         want_logits=False, quantizer_training=None):
+        """Forward (+ backward when compute_grads).  Returns dict(loss_recon, loss_vq, perplexity, acc, recon_ids, indices
+        [, logits]).  dec_ids / dec_mask: the decoder's own input (Bagon.forward takes one; default = the encoder's)."""
+        S = max(input_ids.shape[1], dec_ids.shape[1] if dec_ids is not None else 0)
         if S > 32:
             raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
+        if compute_grads and dec_ids is not None:
+            raise KvqError("TrainEngine: the backward schedule covers the autoencoding step (decoder input = encoder input)")
         self._site_ctr = 0
         self._red_items, self._red_keep = [], []
         self._wg_items, self._wg_keep = [], []
         self._sorted_ids = None
         nnops.set_seed_offset(self._state)        # dropout seeds of this engine's launches = _step_seed + device step count
         try:
-            return self._forward_backward(input_ids, attention_mask, training, compute_grads)
+            self._q_training = training if quantizer_training is None else bool(quantizer_training)
+            with torch.no_grad():            # the schedule IS the backward pass: no autograd graph over the few torch ops in it
+                return self._forward_backward(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits)
         finally:
             nnops.set_seed_offset(None)
 
-    def _forward_backward(self, input_ids, attention_mask, training, compute_grads):
+    def forward_logits(self, enc_ids, enc_mask, dec_ids=None, dec_mask=None, training=False, quantizer_training=None):
+        """Forward only, on the engine's kernels, with the [B, S, V] logits in the result: what Bagon.forward / Shelgon.forward
+        return (models/bagon/Bagon.py:40-55, models/shelgon3/Shelgon.py:50-73)."""
+        self.refresh_if_params_changed()
+        return self.forward_backward(enc_ids, enc_mask, training=training, compute_grads=False, dec_ids=dec_ids, dec_mask=dec_mask,
+                                     want_logits=True, quantizer_training=quantizer_training)
+
+    def _forward_backward(self, input_ids, attention_mask, training, compute_grads, dec_ids=None, dec_mask=None, want_logits=False):
         m = self.model
         fl, H = self.flat, self.H
         B, S = input_ids.shape
         N = B * S
         mask = attention_mask.contiguous()
         ecfg, dcfg = self.ecfg, self.dcfg
+        d_ids = input_ids if dec_ids is None else dec_ids
+        d_mask = mask if dec_mask is None else dec_mask.contiguous()
+        Sd = d_ids.shape[1]
+        Nd = B * Sd
+        if d_ids.shape[0] != B:
+            raise KvqError("TrainEngine: encoder and decoder batches differ")
 
         # ---------------- forward ----------------
         x, emb_saved = self._emb_fwd("enc.emb.", ecfg, input_ids, training)
@@ -802,28 +856,33 @@ class TrainEngine:
             x, ff = self._ffn_fwd(f"enc.{i}.", x, ecfg, training)
             enc_saved.append((sa, ff))
         z = x
-        if self.has_vq:
+        gum_saved = None
+        if self.vq_kind in ("VectorQuantizer", "MultiVectorQuantizer"):
             cap = self._cap
             if cap is not None:                     # graph capture: the quantiser stays an eager launch between two graphs
                 z_q, idx, vq_out = cap.z_q, cap.idx, cap.vq_out
             else:
                 z_q = torch.empty_like(z)
-                idx = torch.empty(N, dtype=torch.int64, device=self.dev)
+                idx = torch.empty(N * self.G, dtype=torch.int64, device=self.dev)
                 vq_out = torch.empty(2, dtype=torch.float32, device=self.dev)
             self._eager(lambda: self._vq_forward(z, z_q, idx, vq_out))
             loss_vq, perplexity = vq_out[0], vq_out[1]
             enc_out = z_q
+            indices = idx.view(self.G, N).t().reshape(B, S, self.G)          # [B, S, 1] for the reference's single codebook
+        elif self.vq_kind == "GumbelQuantizer":
+            enc_out, loss_vq, perplexity, ind, gum_saved = self._gumbel_forward(z, self._q_training)
+            idx, indices = ind, ind.view(B, S)                               # GumbelQuantizer.py:76 returns [B, S]
         else:
-            idx, loss_vq, perplexity, enc_out = None, None, None, z
+            idx, loss_vq, perplexity, enc_out, indices = None, None, None, z, None
 
-        y, demb_saved = self._emb_fwd("dec.emb.", dcfg, input_ids, training, word_rows=None)
+        y, demb_saved = self._emb_fwd("dec.emb.", dcfg, d_ids, training, word_rows=None)
         dec_saved = []
         kv_all = None
         if self._cakv_batched:             # keys | values of every decoder layer's cross-attention in one [N, L*2H] GEMM
             kv_all = torch.addmm(fl.fused(self._cakv_b, fl.shadow), enc_out, fl.fused(self._cakv_w, fl.shadow).t())
         for i in range(self.n_dec_layers):
-            y, sa = self._attn_block_fwd(f"dec.{i}.sa.", y, None, mask, True, dcfg, training, B, S, S)
-            y, ca = self._attn_block_fwd(f"dec.{i}.ca.", y, enc_out, None, False, dcfg, training, B, S, S,
+            y, sa = self._attn_block_fwd(f"dec.{i}.sa.", y, None, d_mask, True, dcfg, training, B, Sd, Sd)
+            y, ca = self._attn_block_fwd(f"dec.{i}.ca.", y, enc_out, None, False, dcfg, training, B, Sd, S,
                                          kv_pre=kv_all[:, 2 * H * i: 2 * H * (i + 1)] if kv_all is not None else None)
             y, ff = self._ffn_fwd(f"dec.{i}.", y, dcfg, training)
             dec_saved.append((sa, ca, ff))
@@ -832,16 +891,19 @@ class TrainEngine:
         Wv = fl.w("dec.emb.word", rows=self.Vp)                              # [Vp,H], rows >= V are zero
         bv = fl.shadow[fl.seg["head.bias"][0]: fl.seg["head.bias"][0] + self.Vp]
         logits = torch.addmm(bv, hN, Wv.t())                                  # [N,Vp]
-        tgt = input_ids.reshape(-1)
-        row_loss = torch.empty(N, dtype=torch.float32, device=self.dev)
-        row_lse = torch.empty(N, dtype=torch.float32, device=self.dev)
-        pred = torch.empty(N, dtype=torch.int64, device=self.dev)
+        tgt = d_ids.reshape(-1)
+        row_loss = torch.empty(Nd, dtype=torch.float32, device=self.dev)
+        row_lse = torch.empty(Nd, dtype=torch.float32, device=self.dev)
+        pred = torch.empty(Nd, dtype=torch.int64, device=self.dev)
         ce_out = torch.empty(2, dtype=torch.float32, device=self.dev)
-        check(lib().kvq_ce_forward(logits.data_ptr(), tgt.data_ptr(), N, self.V, self.Vp, self.io, row_loss.data_ptr(),
+        check(lib().kvq_ce_forward(logits.data_ptr(), tgt.data_ptr(), Nd, self.V, self.Vp, self.io, row_loss.data_ptr(),
                                    row_lse.data_ptr(), pred.data_ptr(), ce_out[0:].data_ptr(), ce_out[1:].data_ptr(), stream_ptr()),
               "kvq_ce_forward")
         out = dict(loss_recon=ce_out[0] * self.w_recon, loss_vq=(loss_vq * self.w_vq) if self.has_vq else None,
-                   perplexity=perplexity, acc=ce_out[1], recon_ids=pred.view(B, S), indices=idx.view(B, S, 1) if idx is not None else None)
+                   perplexity=perplexity, acc=ce_out[1], recon_ids=pred.view(B, Sd), indices=indices)
+        if want_logits:
+            out["logits"] = logits[:, :self.V].reshape(B, Sd, self.V)
+            out["loss_vq_raw"] = loss_vq                          # without the trainer's loss weight
         if not compute_grads:
             return out
 
@@ -905,16 +967,10 @@ class TrainEngine:
             self._grads_done_down_to(self._cakv_w[0])
         self._emb_bwd("dec.emb.", g_y, demb_saved, tied_accumulate=True)
         self._grads_done_down_to("dec.emb.word")
-        if self.has_vq:
-            g_z = torch.empty_like(z)
-            gl = self._ones * self.w_vq
-            ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, self.E.shape[0], H, 1))
-            need_E = self.E.requires_grad
-            check(lib().kvq_vq_backward(z.data_ptr(), self.E.data_ptr(), idx.data_ptr(), g_enc.data_ptr(), gl.data_ptr(), N,
-                                        self.E.shape[0], H, 1, self.io, self.beta_vq, g_z.data_ptr(),
-                                        self.gE.data_ptr() if need_E else None, ws.data_ptr(), ws.numel(), stream_ptr()),
-                  "kvq_vq_backward")
-            g_x = g_z
+        if self.vq_kind in ("VectorQuantizer", "MultiVectorQuantizer"):
+            g_x = self._vq_backward(z, idx, g_enc)
+        elif self.vq_kind == "GumbelQuantizer":
+            g_x = self._gumbel_backward(g_enc, gum_saved)
         else:
             g_x = g_enc
         any_enc = any(v for k, v in tr.items() if k.startswith("enc."))
@@ -929,12 +985,105 @@ class TrainEngine:
         self._flush_reductions()
         return out
 
+    def _buf(self, name, shape, dtype):
+        """Persistent scratch of the eager (between-graphs) launches: same storage every step."""
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.empty(shape, dtype=dtype, device=self.dev)
+        return t
+
     def _vq_forward(self, z, z_q, idx, vq_out):
+        """kvq_vq_forward on the encoder output: one codebook (the reference's VectorQuantizer), or G codebooks on G column
+        slices as one grouped launch (MultiVectorQuantizer: loss / perplexity = mean over the factors)."""
         N, H = z.shape
-        ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, self.E.shape[0], H, 1))
-        check(lib().kvq_vq_forward(z.data_ptr(), self.E.data_ptr(), N, self.E.shape[0], H, 1, self.io, self.beta_vq,
-                                   z_q.data_ptr(), idx.data_ptr(), vq_out[0:].data_ptr(), vq_out[1:].data_ptr(), None,
-                                   ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward")
+        G, K, Dg = self.G, self.K, self.Dg
+        ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, K, Dg, G))
+        if G == 1:
+            check(lib().kvq_vq_forward(z.data_ptr(), self.E.data_ptr(), N, K, H, 1, self.io, self.beta_vq,
+                                       z_q.data_ptr(), idx.data_ptr(), vq_out[0:].data_ptr(), vq_out[1:].data_ptr(), None,
+                                       ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward")
+            zsrc = z
+        else:
+            zg = self._buf("zg", (G, N, Dg), z.dtype)
+            zg.copy_(z.view(N, G, Dg).permute(1, 0, 2))
+            zqg = self._buf("zqg", (G, N, Dg), z.dtype)
+            lp = self._buf("lp", (2, G), torch.float32)
+            check(lib().kvq_vq_forward(zg.data_ptr(), self.E.data_ptr(), N, K, Dg, G, self.io, self.beta_vq,
+                                       zqg.data_ptr(), idx.data_ptr(), lp[0].data_ptr(), lp[1].data_ptr(), None,
+                                       ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward")
+            z_q.view(N, G, Dg).copy_(zqg.permute(1, 0, 2))
+            vq_out.copy_(lp.mean(1))
+            zsrc = zg
+        if self.vq_ema:                      # the EMA step runs after backward: keep what it needs in storage of its own
+            self._buf("ema_z", zsrc.shape, zsrc.dtype).copy_(zsrc)
+            self._buf("ema_idx", idx.shape, idx.dtype).copy_(idx)
+            self._ema_shapes = (tuple(zsrc.shape), zsrc.dtype, tuple(idx.shape))
+
+    def _vq_backward(self, z, idx, g_enc):
+        N, H = z.shape
+        G, K, Dg = self.G, self.K, self.Dg
+        ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, K, Dg, G))
+        gE = self.gE.data_ptr() if self.E.requires_grad else None
+        g_z = torch.empty_like(z)
+        if G == 1:
+            gl = self._ones * self.w_vq
+            check(lib().kvq_vq_backward(z.data_ptr(), self.E.data_ptr(), idx.data_ptr(), g_enc.data_ptr(), gl.data_ptr(), N, K, H, 1,
+                                        self.io, self.beta_vq, g_z.data_ptr(), gE, ws.data_ptr(), ws.numel(), stream_ptr()),
+                  "kvq_vq_backward")
+            return g_z
+        zg = z.view(N, G, Dg).permute(1, 0, 2).contiguous()
+        gq = g_enc.view(N, G, Dg).permute(1, 0, 2).contiguous()
+        gl = torch.full((G,), self.w_vq / G, dtype=torch.float32, device=self.dev)       # loss = mean over the factors
+        gzg = torch.empty_like(zg)
+        check(lib().kvq_vq_backward(zg.data_ptr(), self.E.data_ptr(), idx.data_ptr(), gq.data_ptr(), gl.data_ptr(), N, K, Dg, G,
+                                    self.io, self.beta_vq, gzg.data_ptr(), gE, ws.data_ptr(), ws.numel(), stream_ptr()),
+              "kvq_vq_backward")
+        g_z.view(N, G, Dg).copy_(gzg.permute(1, 0, 2))
+        return g_z
+
+    def _ema_step(self):
+        zs, zdt, ishape = self._ema_shapes
+        z, idx = self._buf("ema_z", zs, zdt), self._buf("ema_idx", ishape, torch.int64)
+        self.model.vector_quantizer.ema_update(z, idx.view(self.G, -1) if self.G > 1 else idx)
+
+    # ---- GumbelQuantizer (models/shelgon3/GumbelQuantizer.py:43-83): 1x1 conv = GEMM, row kernel, codebook GEMM ----------------
+    def _gumbel_forward(self, z, training):
+        gq = self.model.vector_quantizer
+        N, H = z.shape
+        K, dt = gq.n_embed, self.dtype
+        Wp = gq.proj.weight.squeeze(-1).to(dt)                                        # [K, H]
+        logits = torch.addmm(gq.proj.bias.to(dt), z, Wp.t())
+        hard = bool(gq.straight_through) if training else True                       # :54
+        y = torch.empty_like(logits)
+        y_soft = torch.empty((N, K), dtype=torch.float32, device=self.dev)
+        ind = torch.empty(N, dtype=torch.int64, device=self.dev)
+        kl_row = torch.empty(N, dtype=torch.float32, device=self.dev)
+        noise = getattr(self, "gumbel_noise", None)           # tests: explicit Gumbel(0,1) samples [N, K] f32 instead of the Philox stream
+        check(lib().kvq_gumbel_forward(logits.data_ptr(), noise.data_ptr() if noise is not None else None, N, K,
+                                       float(gq.temperature), int(hard), int(self._step_seed), self._site(),
+                                       self.io, y.data_ptr(), y_soft.data_ptr(), ind.data_ptr(), kl_row.data_ptr(), stream_ptr()),
+              "kvq_gumbel_forward")
+        diff = kl_row.mean() * float(gq.kld_scale)                                    # :73
+        emb = gq.embed.weight.to(dt)
+        z_q = y @ emb                                                                 # :66 einsum, already [N, D]
+        used = torch.zeros(K, dtype=torch.float32, device=self.dev).scatter_add_(0, ind, self._ones.expand(N))
+        perplexity = (used > 0).sum().float()                                         # codes in use (Shelgon.py:63)
+        return z_q, diff, perplexity, ind, (z, logits, y, y_soft, Wp, emb)
+
+    def _gumbel_backward(self, g_zq, saved):
+        gq = self.model.vector_quantizer
+        z, logits, y, y_soft, Wp, emb = saved
+        N, K = logits.shape
+        g_y = g_zq @ emb.t()
+        self.g_emb.copy_(y.t() @ g_zq)
+        gd = self._ones.reshape(1) * self.w_vq
+        g_logits = torch.empty_like(logits)
+        check(lib().kvq_gumbel_backward(logits.data_ptr(), y_soft.data_ptr(), g_y.data_ptr(), gd.data_ptr(), N, K, float(gq.temperature),
+                                        float(gq.kld_scale), self.io, g_logits.data_ptr(), stream_ptr()), "kvq_gumbel_backward")
+        self.g_pw.copy_((g_logits.t() @ z).unsqueeze(-1))
+        self.g_pb.copy_(g_logits.float().sum(0))
+        return g_logits @ Wp
 
     def _adam_ranges(self, lo, hi):
         fl = self.flat
@@ -954,6 +1103,8 @@ class TrainEngine:
             cut = self._pending_hi                    # [0, cut) has not been sent yet (embedding gradients)
             self._eager(lambda: self._exchange_head(cut))
             self._pending_hi = fl.n
+        if self.vq_ema:          # the codebook follows the EMA of its assigned encoder outputs (backward has used the old one by now)
+            self._eager(self._ema_step)
         self._step_host += 1
         # step += 1, lr after the milestones, bias corrections: computed on the device, read there by the Adam kernels
         nnops.step_state_advance(self._state, self.lr, self.gamma, self.milestones, b1, b2)
@@ -961,9 +1112,22 @@ class TrainEngine:
         if self.world > 1:
             self._eager(self._exchange_tail)
             self._adam_ranges(0, cut)
-        if self.has_vq and self.E.requires_grad:
-            nnops.adam_step_dev(self.E.data.view(-1), self.gE.view(-1), self.mE.view(-1), self.vE.view(-1), self._state,
-                                b1, b2, self.eps, self.wd, vmax=self.vmaxE.view(-1) if self.vmaxE is not None else None)
+        for a in self.aux:
+            if a["p"].requires_grad:
+                nnops.adam_step_dev(a["p"].data.view(-1), a["g"].view(-1), a["m"].view(-1), a["v"].view(-1), self._state,
+                                    b1, b2, self.eps, self.wd, vmax=a["vmax"].view(-1) if a["vmax"] is not None else None)
+
+
+    def _versions(self):
+        return sum(p._version for p in self.param_of.values())
+
+    def refresh_if_params_changed(self):
+        """Parameters written from outside (an optimiser step of the autograd path, load_state_dict) since the bf16 shadow was
+        last refreshed: refresh it.  The engine's own Adam kernel keeps the shadow current and does not bump tensor versions."""
+        v = self._versions()
+        if v != self._param_versions:
+            self.flat.refresh_shadow()
+            self._param_versions = v
 
     def sync_from_model(self):
         """Call after the model's parameters were written from outside (load_state_dict, manual init): refreshes the bf16
@@ -974,9 +1138,9 @@ class TrainEngine:
     def supports(model, seq_len: int) -> bool:
         """The engine covers BERT-shaped models with 64-wide heads and sentences of at most 32 tokens."""
         cfg = model.encoder.config
-        kind = type(getattr(model, "vector_quantizer", None)).__name__          # the Gumbel quantiser runs on the autograd path
-        return kind in ("VectorQuantizer", "NoneType") and cfg.hidden_size // cfg.num_attention_heads == 64 and seq_len <= 32 \
-            and cfg.hidden_size % 32 == 0
+        kind = type(getattr(model, "vector_quantizer", None)).__name__
+        return kind in _QUANTIZERS + ("NoneType",) and cfg.hidden_size // cfg.num_attention_heads == 64 and seq_len <= 32 \
+            and cfg.hidden_size % 32 == 0 and next(model.parameters()).is_cuda
 
     def _train_step_eager(self, input_ids, attention_mask):
         out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True)

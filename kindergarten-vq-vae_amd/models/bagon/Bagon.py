@@ -9,7 +9,9 @@ Differences by design:
   * model names are resolved OFFLINE: a local directory is loaded with from_pretrained, a known name
     ("bert-base-uncased", ...) is built from its architecture config with random init -- the reference fetches
     weights by name (Bagon.py:25-27), there is no network here;
-  * forward runs kvq.bert's fused plan in bf16 (f32 master weights) instead of HF's module-by-module forward;
+  * forward without autograd runs on the TrainEngine's HIP schedule (kvq/engine.py: own MFMA GEMMs, MFMA attention, fused
+    LayerNorm / GELU kernels, bf16 with f32 master weights); with autograd it runs kvq/bert.py, an ATen restatement of HF's math
+    that torch can differentiate;
     `backend="hf"` keeps HF's own forward reachable (it is the oracle in tests/test_abi_and_host.py::test_bert_plan_equals_huggingface_forward and tests/test_engine_gpu.py::test_hf_forward_kvq_path_and_engine_agree_on_gpu).
 """
 from __future__ import annotations
@@ -31,6 +33,12 @@ LOCAL_BERT_CONFIGS = {
     "kvq-bert-small": dict(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024),
     "kvq-bert-tiny": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                           vocab_size=2048, max_position_embeddings=64),
+    "kvq-bert-tiny-nodrop": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                 vocab_size=2048, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                                 attention_probs_dropout_prob=0.0),
+    # nine 64-wide heads = nine factor slices for the 9-codebook quantiser of BASELINE.json configs[4]
+    "kvq-bert-9x64": dict(hidden_size=576, num_hidden_layers=2, num_attention_heads=9, intermediate_size=2304,
+                          vocab_size=2048, max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0),
     # bert-base widths (768 / 12 heads / 3072 / vocab 30522) with two layers: every GEMM shape of the benchmarked step
     # at a size a parity test can afford (tests/test_engine_base_shapes_gpu.py)
     "kvq-bert-base-2l": dict(num_hidden_layers=2),
@@ -88,7 +96,22 @@ class Bagon(nn.Module):
                                 attention_mask=attention_mask).logits
         return kbert.decoder_forward(self.decoder, input_ids, attention_mask, encoder_hidden_states, self.compute_dtype)
 
+    def _engine_forward_ok(self, *ids) -> bool:
+        """Forward on the TrainEngine's HIP schedule (own GEMMs, MFMA attention, fused LayerNorm / GELU kernels): whenever no
+        autograd graph is wanted and the shapes are the ones the kernels are written for.  With gradients enabled the call goes
+        through kvq/bert.py, the ATen restatement that torch autograd can differentiate (it doubles as the engine's checker)."""
+        if self.backend != "kvq" or torch.is_grad_enabled() or not all(t.is_cuda for t in ids):
+            return False
+        from kvq.engine import TrainEngine
+        return TrainEngine.supports(self, max(t.shape[1] for t in ids))
+
     def forward(self, encoder_input_ids, encoder_attention_mask, decoder_input_ids, decoder_attention_mask):
+        if self._engine_forward_ok(encoder_input_ids, decoder_input_ids):
+            from kvq.engine import engine_of
+            same = decoder_input_ids is encoder_input_ids
+            out = engine_of(self).forward_logits(encoder_input_ids, encoder_attention_mask, None if same else decoder_input_ids,
+                                                 None if same else decoder_attention_mask, training=self.training)
+            return out["logits"]
         encoder_output = self.encode(encoder_input_ids, encoder_attention_mask)            # Bagon.py:46-48
         return self.decode(encoder_output, decoder_input_ids, decoder_attention_mask)      # Bagon.py:50-55
 

@@ -44,15 +44,22 @@ class Shelgon(Bagon):
         if kind == "VectorQuantizer":
             vq_loss, z_q, perplexity, _enc, indices = self.vector_quantizer.forward(embeds.contiguous(), device)
             return vq_loss, z_q, perplexity, indices
+        if kind == "MultiVectorQuantizer":                                         # extension: G codebooks, one grouped launch
+            vq_loss, z_q, perplexity, _enc, indices = self.vector_quantizer.forward(embeds.contiguous(), device)
+            return vq_loss, z_q, perplexity, indices
         if kind == "GumbelQuantizer":                                              # Shelgon.py:60-65
             z_q, vq_loss, indices = self.vector_quantizer.forward(embeds, self.training)
             # "not the actual perplexity computation, but still informative" (Shelgon.py:63): number of codes in use,
             # counted on the device instead of through a .cpu() copy
             perplexity = torch.unique(indices).numel()
             return vq_loss, z_q.to(embeds.dtype), torch.tensor(float(perplexity), device=embeds.device), indices
-        raise ValueError(f"{kind} vector quantizer mode NOT supported. Supported modalities: VectorQuantizer, GumbelQuantizer")
+        raise ValueError(f"{kind} vector quantizer mode NOT supported. Supported modalities: VectorQuantizer, GumbelQuantizer, MultiVectorQuantizer")
 
     def forward(self, input_ids, attention_mask, device=None, is_training: bool = True):
+        if self._engine_forward_ok(input_ids):                                     # no autograd graph wanted: HIP end to end
+            from kvq.engine import engine_of
+            out = engine_of(self).forward_logits(input_ids, attention_mask, training=self.training, quantizer_training=is_training)
+            return out["loss_vq_raw"], out["perplexity"], out["indices"], out["logits"]
         embeds = self.encode(input_ids, attention_mask)                            # Shelgon.py:52
         vq_loss, z_q, perplexity, indices = self._quantize(embeds, device)
         logits = self.decode(z_q, input_ids, attention_mask)                       # Shelgon.py:71

@@ -11,7 +11,25 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from kvq.functional import vector_quantize, vq_one_hot
+from kvq.functional import vector_quantize, vq_ema_update, vq_one_hot
+
+
+def ema_codebook_update(z, idx, ema_n, ema_m, E, decay, eps):
+    """EMA codebook update (extension named by BASELINE.json, absent from the reference, default off): kvq_vq_ema_update on
+    the local tokens, then -- data parallel -- the running statistics are averaged over the ranks (the update is linear in
+    the per-batch counts / sums, so this equals the update from the global batch's mean statistics) and the codebook is
+    rebuilt from them with the kernel's formula (include/kvq.h).  z [N,D] or [G,N,D]; idx [N] or [G,N]."""
+    import torch.distributed as dist
+    with torch.no_grad():
+        vq_ema_update(z, idx, ema_n, ema_m, E, decay, eps)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            for t in (ema_n, ema_m):
+                dist.all_reduce(t)
+                t.div_(dist.get_world_size())
+            K = ema_n.shape[-1]
+            tot = ema_n.sum(-1, keepdim=True)
+            n = (ema_n + eps) / (tot + K * eps) * tot
+            E.copy_(ema_m / n.unsqueeze(-1))
 
 
 class VectorQuantizer(nn.Module):
@@ -21,7 +39,7 @@ class VectorQuantizer(nn.Module):
     reference's loss (VectorQuantizer.py:76-77: `mean((sg[z_q]-z)^2) + beta*mean((z_q-sg[z])^2)`).
     """
 
-    def __init__(self, n_e, e_dim, beta, vq_codebook_init_values: Tensor = None):
+    def __init__(self, n_e, e_dim, beta, vq_codebook_init_values: Tensor = None, ema_decay: float = None, ema_eps: float = 1e-5):
         super().__init__()
         self.n_e = n_e
         self.e_dim = e_dim
@@ -31,6 +49,13 @@ class VectorQuantizer(nn.Module):
             self.embedding.weight.data.copy_(vq_codebook_init_values)
         else:                                                         # reference :29
             self.embedding.weight.data.uniform_(-1.0 / self.n_e, 1.0 / self.n_e)
+        # Extension (not in the reference, off unless asked for): the codebook follows an exponential moving average of the
+        # encoder outputs assigned to each code instead of the gradient of the loss term at reference :76-77.
+        self.ema_decay, self.ema_eps = ema_decay, ema_eps
+        if ema_decay is not None:
+            self.embedding.weight.requires_grad_(False)
+            self.register_buffer("ema_n", torch.ones(n_e))
+            self.register_buffer("ema_m", self.embedding.weight.data.clone())
         # The reference always builds min_encodings [N,K]; its only caller drops it (Shelgon.py:58).  Keep the
         # contract by default, let the training path switch the 4*N*K-byte write off.
         self.materialize_min_encodings = True
@@ -53,7 +78,13 @@ class VectorQuantizer(nn.Module):
             weight = weight.float()
         loss, z_q, perplexity, idx, counts = vector_quantize(z.view(-1, self.e_dim), weight, self.beta)
         self.last_code_counts = counts
+        if self.ema_decay is not None and self.training:
+            self.ema_update(z.detach().view(-1, self.e_dim), idx)
         z_q = z_q.view(z.shape)
         min_encodings = vq_one_hot(idx, self.n_e) if self.materialize_min_encodings else None
         min_encoding_indices = idx.reshape(batch_size, seq_len, 1)
         return loss, z_q, perplexity, min_encodings, min_encoding_indices
+
+    def ema_update(self, z2d, idx):
+        """One EMA step of the codebook from the tokens z2d [N, e_dim] and their codes idx [N] (training steps only)."""
+        ema_codebook_update(z2d, idx, self.ema_n, self.ema_m, self.embedding.weight.data, float(self.ema_decay), float(self.ema_eps))

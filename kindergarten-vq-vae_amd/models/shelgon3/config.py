@@ -34,7 +34,9 @@ MODEL_MODE = "full"                  # full | dec-head-ft | enc-head-ft-dec-head
 COMPUTE_DTYPE = "bfloat16"           # bfloat16 | float32
 USE_ENGINE = True                    # kvq.engine.TrainEngine (explicit fwd/bwd on flat buffers) when the model shape allows
 
-VQ_MODE = "VectorQuantizer"
+VQ_MODE = "VectorQuantizer"          # VectorQuantizer | GumbelQuantizer | MultiVectorQuantizer (extension: VQ_N_FACTORS codebooks)
+VQ_N_FACTORS = 1                     # MultiVectorQuantizer: codebooks = slices of the encoder output (must divide VQ_E_DIM)
+VQ_EMA_DECAY = None                  # extension, default off: EMA codebook update instead of the codebook gradient (e.g. 0.99)
 VQ_N_E = 512
 VQ_E_DIM = 768
 VQ_BETA = 0.25

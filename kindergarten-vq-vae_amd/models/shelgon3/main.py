@@ -38,6 +38,7 @@ from kvq.tokenizer import load_tokenizer  # noqa: E402
 from models.shelgon3.Shelgon import Shelgon  # noqa: E402
 from models.shelgon3.Trainer import test, train  # noqa: E402
 from models.shelgon3.GumbelQuantizer import GumbelQuantizer  # noqa: E402
+from models.shelgon3.MultiVectorQuantizer import MultiVectorQuantizer  # noqa: E402
 from models.shelgon3.VectorQuantizer import VectorQuantizer  # noqa: E402
 
 
@@ -70,8 +71,12 @@ def main():
 
     if VQ_MODE == "VectorQuantizer":
         init = torch.load(VQ_CODEBOOK_INIT_VALUES_PATH)["codebook_init_values"] if VQ_CODEBOOK_INIT_VALUES_PATH else None
-        vector_quantizer = VectorQuantizer(n_e=VQ_N_E, e_dim=VQ_E_DIM, beta=VQ_BETA, vq_codebook_init_values=init)
+        vector_quantizer = VectorQuantizer(n_e=VQ_N_E, e_dim=VQ_E_DIM, beta=VQ_BETA, vq_codebook_init_values=init,
+                                           ema_decay=VQ_EMA_DECAY)
         vector_quantizer.materialize_min_encodings = False          # the model drops min_encodings (Shelgon.py:58)
+    elif VQ_MODE == "MultiVectorQuantizer":                         # extension (BASELINE.json configs[4]), off by default
+        vector_quantizer = MultiVectorQuantizer(n_factors=VQ_N_FACTORS, n_e=VQ_N_E, e_dim=VQ_E_DIM, beta=VQ_BETA,
+                                                ema_decay=VQ_EMA_DECAY)
     elif VQ_MODE == "GumbelQuantizer":                              # main.py:68-73
         vector_quantizer = GumbelQuantizer(enc_out_size=ENC_OUT_SIZE, n_embed=VQ_N_E, embedding_dim=VQ_E_DIM,
                                            temperature=VQ_TEMPERATURE, kl_div_scale=VQ_KL_DIV_SCALE,
@@ -100,7 +105,7 @@ def main():
     opt = Adam(params=[p for p in model.parameters()], lr=LR, weight_decay=WEIGHT_DECAY, amsgrad=AMSGRAD, fused=True)
     lr_sched = MultiStepLR(optimizer=opt, milestones=MILESTONES, gamma=GAMMA) if LR_SCHEDULER == "MultiStepLR" else None
     engine = grad_sync = None
-    if USE_ENGINE and VQ_MODE == "VectorQuantizer" and TrainEngine.supports(model, TOKENIZED_SENTENCE_MAX_LENGTH):
+    if USE_ENGINE and TrainEngine.supports(model, TOKENIZED_SENTENCE_MAX_LENGTH):
         # explicit forward/backward schedule on flat buffers (kvq/engine.py): owns Adam, the scheduler tick and the
         # RCCL gradient exchange; `opt` above is then only the reference-shaped handle recorded in run_conf.json
         engine = TrainEngine(model, lr=LR, weight_decay=WEIGHT_DECAY, amsgrad=AMSGRAD,

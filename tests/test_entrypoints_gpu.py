@@ -99,7 +99,7 @@ def test_codebook_init_script_feeds_shelgon_main(tmp_path):
 
 
 def test_shelgon_main_gumbel_mode(tmp_path):
-    """VQ_MODE = "GumbelQuantizer" (reference main.py:68-73): the run trains through the autograd path and writes the usual artefacts."""
+    """VQ_MODE = "GumbelQuantizer" (reference main.py:68-73): the run trains on the TrainEngine (Gumbel row kernel between the two BERT stacks) and writes the usual artefacts."""
     run = _run("models/shelgon3/main.py", tmp_path, lambda d: {
         "KVQ_SENTENCES_PATH": repr(d + "/dSentences_sentences_clean.npy"),
         "KVQ_LATENT_CLASSES_LABELS_PATH": repr(d + "/dSentences_latent_classes_labels_clean.npy"),
@@ -111,3 +111,21 @@ def test_shelgon_main_gumbel_mode(tmp_path):
     logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
     perp = [l["train/metric_perp"] for l in logs if "train/metric_perp" in l]
     assert perp and 1 <= perp[0] <= 16            # "perplexity" of this mode = number of codes in use (Shelgon.py:63-65)
+
+
+def test_shelgon_main_multi_codebook_with_ema(tmp_path):
+    """Extensions of BASELINE.json configs[4], selectable from config.py and off by default: VQ_MODE = "MultiVectorQuantizer"
+    (4 factor slices -> one grouped launch) with VQ_EMA_DECAY: the run trains on the TrainEngine, the codebook moves by EMA only."""
+    run = _run("models/shelgon3/main.py", tmp_path, lambda d: {
+        "KVQ_SENTENCES_PATH": repr(d + "/dSentences_sentences_clean.npy"),
+        "KVQ_LATENT_CLASSES_LABELS_PATH": repr(d + "/dSentences_latent_classes_labels_clean.npy"),
+        "KVQ_LATENT_CLASSES_ONE_HOT_PATH": repr(d + "/dSentences_latent_classes_one_hot_clean.npy"),
+        "KVQ_VQ_MODE": "'MultiVectorQuantizer'", "KVQ_VQ_N_FACTORS": "4", "KVQ_VQ_EMA_DECAY": "0.99", "KVQ_VQ_N_E": "16",
+        "KVQ_VQ_E_DIM": "128", "KVQ_N_EPOCHS": "1"})
+    conf = json.load(open(run + "/run_conf.json"))
+    assert conf["vq_mode"] == "MultiVectorQuantizer" and conf["vq_n_factors"] == 4 and conf["vq_ema_decay"] == 0.99
+    sd = torch.load(run + "/shelgon_ckpt_loss_recon_val_best.pth", map_location="cpu")["model_state_dict"]
+    assert sd["vector_quantizer.embedding.weight"].shape == (4 * 16, 32) and sd["vector_quantizer.ema_n"].shape == (4, 16)
+    assert not torch.allclose(sd["vector_quantizer.ema_n"], torch.ones(4, 16))          # the EMA statistics moved
+    logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
+    assert any("train/loss_vq" in l for l in logs)
