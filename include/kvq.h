@@ -70,8 +70,12 @@ int kvq_device_info(int* cu_count, char* name, size_t name_len);
  *   counts   [G,K]   f32        code usage histogram = sum(min_encodings,0); may be NULL
  *   ws                         scratch of kvq_vq_workspace_bytes(N,K,D,G) bytes, 256-byte aligned
  *
- * One fused kernel per call does distances, argmin, gather, straight-through, per-token loss terms and
- * the histogram; a second, single-workgroup kernel turns the partials into loss / perplexity.
+ * What runs per call on the fast path (D %% 32 == 0): the f32-MFMA distance / arg-min kernel (64-bit integer atomicMin per
+ * token), the HBM-bound epilogue kernel (gather, straight-through, per-token loss terms, histogram) and a single-workgroup
+ * kernel that turns the partials into loss / perplexity in a fixed order -- plus, in kvq_vq_forward only, the re-layout of
+ * the codebook in MFMA-fragment order.  A caller that quantises with one codebook many times between its updates (a
+ * training loop: one update per optimiser step) keeps that copy itself: kvq_vq_pack_codebook after every codebook update,
+ * kvq_vq_forward_packed per step.  Other D: one generic kernel (one wave per token) + the same finalize.
  * min_encodings ([N,K] one-hot, :67-68) is not produced here: see kvq_vq_one_hot.
  */
 size_t kvq_vq_workspace_bytes(int64_t N, int K, int D, int G);
@@ -79,6 +83,12 @@ size_t kvq_vq_workspace_bytes(int64_t N, int K, int D, int G);
 int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G, int io_dtype, float beta,
                    void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts,
                    void* ws, size_t ws_bytes, void* stream);
+/* packed: kvq_vq_packed_bytes(K, D, G) bytes, 16-byte aligned, written by kvq_vq_pack_codebook from the SAME E (D %% 32 == 0). */
+size_t kvq_vq_packed_bytes(int K, int D, int G);
+int kvq_vq_pack_codebook(const float* E, int K, int D, int G, float* packed, void* stream);
+int kvq_vq_forward_packed(const void* z, const float* E, const float* packed, int64_t N, int K, int D, int G, int io_dtype,
+                          float beta, void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts,
+                          void* ws, size_t ws_bytes, void* stream);
 
 /* Autograd of the above (implicit in the reference; closed form in SURVEY.md §8 row A8b):
  *   g_z  = g_zq - s*fl(e_idx - z),            s = g_loss * 2/(N*D)
@@ -109,19 +119,6 @@ int kvq_prof_read(float* ms_host, int max);
 
 /* Which path kvq_vq_forward takes for a shape: 1 = f32-MFMA LDS-tiled kernel, 0 = generic kernel. */
 int kvq_vq_uses_mfma(int64_t N, int K, int D);
-
-/* Tuning / A-B switch between the two MFMA forward structures (both bit-identical in results):
- *   2 (default) = 2-D tiled distance kernel (32 tokens x 128 codes per workgroup, 4 workgroups per CU, 64-bit
- *                 atomicMin hand-over) + streaming epilogue kernel;   1 = single fused kernel (32 tokens x all codes). */
-int kvq_vq_set_forward_variant(int variant);
-/* Tuning knobs of the tiled distance kernel (results are bit-identical for every setting): kc = contraction floats per LDS
- * stage (32: 40 KiB LDS, 4 workgroups/CU; 64: 80 KiB, 2 workgroups/CU); prio != 0 raises wave priority around the MFMA cluster;
- * packed != 0 uses the variant whose codebook operand is pre-packed in MFMA-fragment order and streamed global -> VGPR
- * (only the token tile goes through LDS): 1 = one 32-token tile per wave, 2 (default) = two tiles per wave sharing each
- * codebook fragment (64 tokens x 128 codes per workgroup). */
-int kvq_vq_set_tuning(int kc, int prio, int packed);
-/* Diagnostics: resident workgroups per CU the runtime reports for the two forward kernels at their LDS sizes. */
-int kvq_vq_debug_occupancy(int* blocks_per_cu_tiled, int* blocks_per_cu_fused);
 
 /* EMA codebook update (extension named by BASELINE.json north_star; NOT in the reference -> default off):
  *   n_k <- g*n_k + (1-g)*count_k ;  m_k <- g*m_k + (1-g)*sum_{idx_n=k} z_n ;

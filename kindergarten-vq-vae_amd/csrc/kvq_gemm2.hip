@@ -299,6 +299,19 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
 #pragma unroll
         for (int ni = 0; ni < C::FB; ++ni) acc[mi][ni] = 0.f;
 
+    // the bias values this lane will add in the epilogue: requested now, FB dependent round trips to L2 later otherwise
+    u16x4 biasv[C::FB];
+    {
+        const int fk0 = lane >> 4;
+#pragma unroll
+        for (int ni = 0; ni < C::FB; ++ni) {
+            int nb = n0 + wn * C::TN + ni * 16 + 4 * fk0;
+            nb = nb + 4 <= pr.N ? nb : pr.N - 4;
+            const u16x4 zero = {0, 0, 0, 0};
+            biasv[ni] = pr.bias ? *reinterpret_cast<const u16x4*>(pr.bias + nb) : zero;
+        }
+    }
+
     // ---- prologue: fill the ring
     Stager<C> sg;
     sg.init(pr, smem, m0, n0, w, lane);
@@ -314,7 +327,9 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
     //   MFMA(f1) || read next f0 || 1st half of the refill of the slot just freed
     Frags<C> f0, f1;
     read_frags<C>(f0, smem, wm, wn, 0, lane);
-    constexpr int PH = C::PPW / 2;                                         // pieces issued inside the first cluster after the barrier
+    // pieces issued inside the first cluster after the barrier; a two-slot ring needs the whole refill there (the tile is
+    // waited for at the very next barrier), a deeper ring spreads it over both clusters
+    constexpr int PH = C::NS == 2 ? C::PPW : C::PPW / 2;
     int slot = 0, pslot = 0;
     bool pending = false;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -367,13 +382,8 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
 #pragma unroll
     for (int ni = 0; ni < C::FB; ++ni) {
         const int nl = wn * C::TN + ni * 16 + 4 * fk;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (pr.bias) {
-            int nb = n0 + nl;
-            nb = nb + 4 <= pr.N ? nb : pr.N - 4;
-            const u16x4 t = *reinterpret_cast<const u16x4*>(pr.bias + nb);
-            bv.x = bf16_to_f32(t.x); bv.y = bf16_to_f32(t.y); bv.z = bf16_to_f32(t.z); bv.w = bf16_to_f32(t.w);
-        }
+        const u16x4 t = biasv[ni];
+        const f32x4 bv = {bf16_to_f32(t.x), bf16_to_f32(t.y), bf16_to_f32(t.z), bf16_to_f32(t.w)};
 #pragma unroll
         for (int mi = 0; mi < C::FA; ++mi) {
             const int ml = wm * C::TM + mi * 16 + frow;

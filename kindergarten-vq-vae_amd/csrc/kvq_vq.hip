@@ -3,18 +3,21 @@
 // Replaces models/shelgon3/VectorQuantizer.py:55-93 of the reference (distance, argmin, one-hot gather,
 // losses, straight-through, perplexity) and its autograd.  Numerics contract: include/kvq.h ("kvq order v1").
 //
-// Forward, fast path (D % 64 == 0): ONE fused kernel per call.
-//   workgroup = 32 tokens x all K codes, 8 waves (2 per SIMD); codes are swept 256 per pass, the contraction
-//   64 floats per stage.  Each stage's E tile [256 codes][64] and z tile [32 tokens][64] sit in LDS as 256-byte
-//   rows, 16-byte chunks XOR-swizzled by (row & 15) so that the ds_read_b128 fragment reads are conflict free;
-//   two stages are double buffered (144 KiB of the CU's 160 KiB) while the next stage's global loads are in
-//   flight.  The contraction runs on the exact-f32 matrix core instruction v_mfma_f32_32x32x2_f32 with the CODES
-//   as rows: a lane then owns one token and 16 codes of the 32x32 tile, so the running argmin is lane-local;
-//   the two half-waves are merged with one shuffle and the 8 waves through 2 KiB of LDS.  Row norms ||e||^2 and
-//   ||z||^2 fall out of the operand fragments the lanes already hold (one extra fmaf per operand element).
-//   Epilogue in the same kernel: gather E[idx], z_q = z + (e - z), per-token sum of squares (f64), histogram.
-//   A single-workgroup kernel then reduces the per-token terms to loss and perplexity in a fixed order
-//   (bitwise reproducible; no float atomics anywhere).
+// Forward, fast path (D % 32 == 0), three launches per call (+ one re-layout of the codebook per codebook UPDATE):
+//   vq_dist_packed_kernel   the distance contraction on the exact-f32 matrix core instruction v_mfma_f32_32x32x2_f32 with the
+//                           codes as MFMA rows (a lane owns one token and 16 codes of a 32x32 tile: the running arg-min is
+//                           lane-local); workgroup = 64 tokens x 128 codes, 4 waves, the codebook operand streamed
+//                           global -> VGPR from an MFMA-fragment-ordered copy, only the token tile staged through LDS; the
+//                           per-token minimum leaves as ONE 64-bit integer atomicMin on (orderable(d) << 32 | code)
+//   vq_epilogue_kernel      HBM-bound: gather E[idx], z_q = z + (e - z), per-token sum of squares (f64), histogram
+//   vq_finalize_kernel      one workgroup: loss and perplexity from the partials in a fixed order (bitwise reproducible; no
+//                           float atomics anywhere)
+//   vq_pack_codebook_kernel the fragment-ordered codebook copy: once per optimiser step through kvq_vq_pack_codebook +
+//                           kvq_vq_forward_packed (the engine), or inside kvq_vq_forward for one-off calls.
+// Measured alternatives that lost and were removed in round 2 (profiles/r01_summary.md): one fused kernel over all codes
+// (32 tokens x K per workgroup: 100 us against 62 + 14.5 us at N = 8192, K = 512, D = 768) and the codebook staged through
+// LDS (73 us).  Folding the epilogue into the distance kernel needs every code block of a token finished first, i.e. a
+// workgroup per token tile over ALL codes -- the 100-us structure.
 // Forward, generic path (any D): one wave per token, same chain orders, scalar fmaf.
 // Backward: g_z elementwise; g_E by ordered slab reduction (per code, per token chunk, then chunks in order).
 #include <limits.h>
@@ -23,23 +26,6 @@
 #include "kvq_common.h"
 
 namespace kvq {
-
-// =============================================================================================================
-// geometry of the fused MFMA kernel
-// =============================================================================================================
-constexpr int TM = 32;                 // tokens per workgroup
-constexpr int NWAVES = 8;              // waves per workgroup (2 per SIMD)
-constexpr int NTHREADS = NWAVES * WAVE;
-constexpr int CP = NWAVES * 32;        // codes per pass (one 32x32 tile per wave)
-constexpr int KC = 64;                 // contraction depth per stage, floats (256-byte LDS rows)
-constexpr int E_TILE = CP * KC;        // floats
-constexpr int Z_TILE = TM * KC;        // floats
-constexpr int STAGE = E_TILE + Z_TILE; // floats per stage: 18432 = 72 KiB
-constexpr int RED_OFF = 2 * STAGE;     // cross-wave argmin scratch behind the two stages
-constexpr int LDS_FLOATS = RED_OFF + 2 * NWAVES * TM + TM;
-constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-constexpr int E_CHUNKS_PER_THREAD = (CP * (KC / 4)) / NTHREADS;  // 8 16-byte chunks of E per thread per stage
-static_assert(TM * (KC / 4) == NTHREADS, "one z chunk per thread per stage");
 
 struct FwdParams {
     const void* z;      // [G,N,D] io dtype
@@ -91,208 +77,15 @@ __device__ __forceinline__ void token_epilogue(const FwdParams& p, int g, int64_
     }
 }
 
-// -------------------------------------------------------------------------------------------------------------
-// staging helpers of the fused kernel (register staged: global -> VGPR early, VGPR -> LDS late)
-// -------------------------------------------------------------------------------------------------------------
-template <int DT>
-__device__ __forceinline__ void stage_issue(const FwdParams& p, const float* __restrict__ E, size_t zbase,
-                                            int64_t tok0, int pass, int kc, int tid,
-                                            f32x4 (&er)[E_CHUNKS_PER_THREAD], f32x4& zr) {
-#pragma unroll
-    for (int q = 0; q < E_CHUNKS_PER_THREAD; ++q) {
-        const int L = q * NTHREADS + tid;
-        const int r = L >> 4, c = L & 15;
-        int code = pass * CP + r;
-        code = code < p.K ? code : p.K - 1;   // padding rows: any valid row, masked out at the argmin
-        er[q] = *reinterpret_cast<const f32x4*>(E + (size_t)code * p.D + kc * KC + c * 4);
-    }
-    const int r = tid >> 4, c = tid & 15;
-    // unconditional load from a clamped row + select: a branch around the load would make hipcc wait vmcnt(0) right
-    // behind it and serialise the whole prefetch with the MFMA cluster
-    const int64_t tok = tok0 + r;
-    const int64_t tokc = tok < p.N ? tok : p.N - 1;
-    const f32x4 zv = IO<DT>::load4(p.z, zbase + (size_t)tokc * p.D + kc * KC + c * 4);
-    const float m = tok < p.N ? 1.0f : 0.0f;
-    zr = zv * m;
-}
-
-__device__ __forceinline__ void stage_commit(float* sb, int tid, const f32x4 (&er)[E_CHUNKS_PER_THREAD],
-                                             const f32x4& zr) {
-#pragma unroll
-    for (int q = 0; q < E_CHUNKS_PER_THREAD; ++q) {
-        const int L = q * NTHREADS + tid;
-        const int r = L >> 4, c = L & 15;
-        *reinterpret_cast<f32x4*>(sb + r * KC + ((c ^ (r & 15)) << 2)) = er[q];
-    }
-    const int r = tid >> 4, c = tid & 15;
-    *reinterpret_cast<f32x4*>(sb + E_TILE + r * KC + ((c ^ (r & 15)) << 2)) = zr;
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// the fused forward kernel (fast path)
-// -------------------------------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(NTHREADS) void vq_fwd_mfma_kernel(FwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int w = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
-    const int g = blockIdx.y;
-    const int64_t tok0 = (int64_t)blockIdx.x * TM;
-    const float* __restrict__ E = p.E + (size_t)g * p.K * p.D;
-    const size_t zbase = (size_t)g * p.N * p.D;
-
-    const int nkc = p.D / KC;
-    const int npass = (p.K + CP - 1) / CP;
-    const int nst = npass * nkc;
-
-    f32x4 er[E_CHUNKS_PER_THREAD];
-    f32x4 zr;
-    stage_issue<DT>(p, E, zbase, tok0, 0, 0, tid, er, zr);
-    stage_commit(smem, tid, er, zr);
-    __syncthreads();
-
-    float best = INFINITY;
-    int bidx = INT_MAX;
-    f32x16 acc;
-    float pe = 0.f, pz = 0.f;
-    int pass = 0, kc = 0;
-
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        const bool more = st + 1 < nst;
-        int npass_next = pass, nkc_next = kc + 1;
-        if (nkc_next == nkc) { nkc_next = 0; npass_next = pass + 1; }
-        if (more) stage_issue<DT>(p, E, zbase, tok0, npass_next, nkc_next, tid, er, zr);
-
-        if (kc == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            pe = 0.f;
-            pz = 0.f;
-        }
-        // ---- 32 MFMAs: D[code][token] += E[code][k] * z[token][k], k = this stage's 64 floats in walk order
-        const float* sb = smem + buf * STAGE;
-        const float* erow = sb + (w * 32 + i) * KC;
-        const float* zrow = sb + E_TILE + i * KC;
-#pragma unroll
-        for (int gq = 0; gq < KC / 8; ++gq) {
-            const int slot = ((2 * gq + h) ^ (i & 15)) << 2;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(erow + slot);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(zrow + slot);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-            pe = __builtin_fmaf(a.x, a.x, pe); pe = __builtin_fmaf(a.y, a.y, pe);
-            pe = __builtin_fmaf(a.z, a.z, pe); pe = __builtin_fmaf(a.w, a.w, pe);
-            pz = __builtin_fmaf(b.x, b.x, pz); pz = __builtin_fmaf(b.y, b.y, pz);
-            pz = __builtin_fmaf(b.z, b.z, pz); pz = __builtin_fmaf(b.w, b.w, pz);
-        }
-
-        if (more) stage_commit(smem + (buf ^ 1) * STAGE, tid, er, zr);
-
-        if (kc == nkc - 1) {
-            // ---- end of a pass: distances of this wave's 32 codes x 32 tokens, lane-local running argmin
-            const float z2 = pz + __shfl_xor(pz, 32, WAVE);   // sq(z_token): lanes i and i+32 hold the halves
-            const float e2v = pe + __shfl_xor(pe, 32, WAVE);  // sq(e_code i) of this wave's tile, in lanes i, i+32
-            const int cbase = pass * CP + w * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;   // row of the 32x32 C/D tile held in register r
-                const float e2r = __shfl(e2v, cl, WAVE);
-                const float t = z2 + e2r;                        // sum(z^2) + sum(e^2)      (:59-60)
-                const float dd = t - 2.0f * acc[r];              // ... - 2 z.e              (:61)
-                const int code = cbase + cl;
-                if (code < p.K) {
-                    if (p.dump && tok0 + i < p.N) p.dump[(size_t)(tok0 + i) * p.K + code] = dd;
-                    if (cand_better(dd, code, best, bidx)) { best = dd; bidx = code; }
-                }
-            }
-        }
-        __syncthreads();
-        kc = nkc_next;
-        pass = npass_next;
-    }
-
-    // ---- merge the two half-waves (same token, interleaved code sets), then the 8 waves through LDS
-    {
-        const float ob = __shfl_xor(best, 32, WAVE);
-        const int oi = __shfl_xor(bidx, 32, WAVE);
-        if (cand_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
-    }
-    float* red_val = smem + RED_OFF;
-    int* red_idx = reinterpret_cast<int*>(smem + RED_OFF + NWAVES * TM);
-    int* fin_idx = reinterpret_cast<int*>(smem + RED_OFF + 2 * NWAVES * TM);
-    if (lane < 32) {
-        red_val[w * TM + i] = best;
-        red_idx[w * TM + i] = bidx;
-    }
-    __syncthreads();
-    if (tid < TM) {
-        float b = red_val[tid];
-        int bi = red_idx[tid];
-#pragma unroll
-        for (int ww = 1; ww < NWAVES; ++ww) {
-            const float v = red_val[ww * TM + tid];
-            const int vi = red_idx[ww * TM + tid];
-            if (cand_better(v, vi, b, bi)) { b = v; bi = vi; }
-        }
-        fin_idx[tid] = bi;
-    }
-    __syncthreads();
-    // histogram: one atomic per DISTINCT code of this workgroup's 32 tokens (a collapsed codebook would otherwise
-    // send every token's atomic to the same address, which serialises at the memory side)
-    if (tid < TM && tok0 + tid < p.N) {
-        const int c = fin_idx[tid];
-        unsigned cnt = 0;
-        bool first = true;
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const bool same = (tok0 + j < p.N) && fin_idx[j] == c;
-            cnt += same ? 1u : 0u;
-            first = first && !(same && j < tid);
-        }
-        if (first) atomicAdd(p.counts + (size_t)g * p.K + c, cnt);
-    }
-
-    // ---- epilogue: each wave finishes 4 tokens
-#pragma unroll 1
-    for (int t = 0; t < TM / NWAVES; ++t) {
-        const int ti = w * (TM / NWAVES) + t;
-        const int64_t tok = tok0 + ti;
-        if (tok < p.N) token_epilogue<DT, false>(p, g, tok, fin_idx[ti], lane);
-    }
-}
-
 // =============================================================================================================
-// v2 fast path: 2-D tiled distance/argmin kernel + streaming epilogue kernel
-//
-//   grid (N/32, K/128, G), 256 threads = 4 waves (one per SIMD), 40 KiB LDS  ->  4 workgroups per CU whose
-//   waves are NOT barrier-coupled to each other: while one workgroup waits on its stage hand-over, the other
-//   three keep the SIMD's matrix pipe busy.  Each workgroup owns 32 tokens x 128 codes over the whole contraction
-//   (24 stages of 32 floats; rows are 128 B, 16-byte chunks swizzled by ((row >> 1) & 7) -> conflict-free
-//   ds_read_b128).  Its per-token minimum goes to global memory as ONE 64-bit atomicMin per token on the key
+// fast path: distance / arg-min kernel (codes as MFMA rows) + streaming epilogue kernel
+//   the per-token minimum goes to global memory as ONE 64-bit atomicMin per token on the key
 //   (orderable(d) << 32 | code): minimum distance first, lowest code on ties, NaN mapped to key 0 (torch.argmin).
 //   The epilogue kernel (HBM-bound) decodes the keys: gather, straight-through, squared error, histogram.
 // =============================================================================================================
-constexpr int T2_TM = 32;
 constexpr int T2_WAVES = 4;
 constexpr int T2_THREADS = T2_WAVES * WAVE;
 constexpr int T2_CN = T2_WAVES * 32;          // 128 codes per workgroup
-
-// stage geometry, parameterised by the contraction depth per stage KC (32 -> 40 KiB LDS, 4 WG/CU; 64 -> 80 KiB, 2 WG/CU)
-template <int KC> struct T2 {
-    static constexpr int CH = KC / 4;                         // 16-byte chunks per row
-    static constexpr int E_TILE = T2_CN * KC;                 // floats
-    static constexpr int STAGE = (T2_CN + T2_TM) * KC;        // floats
-    static constexpr size_t LDS_BYTES = 2 * STAGE * sizeof(float);
-    static constexpr int E_CHUNKS = (T2_CN * CH) / T2_THREADS;
-    static constexpr int Z_CHUNKS = (T2_TM * CH) / T2_THREADS;
-    static constexpr int WGS_PER_CU = KC == 32 ? 4 : 2;
-    // XOR swizzle of the 16-byte chunk index by the row: conflict-free ds_read_b128 for 32 consecutive rows
-    __device__ static __forceinline__ int swz(int r) { return KC == 32 ? ((r >> 1) & 7) : (r & 15); }
-};
-static_assert(T2<32>::Z_CHUNKS == 1 && T2<64>::Z_CHUNKS == 2, "z chunks per thread");
 
 __device__ __forceinline__ unsigned long long pack_key(float d, int code) {
     unsigned u = __float_as_uint(d);
@@ -300,145 +93,9 @@ __device__ __forceinline__ unsigned long long pack_key(float d, int code) {
     return ((unsigned long long)key << 32) | (unsigned)code;
 }
 
-template <int DT, int KC>
-__device__ __forceinline__ void t2_issue(const FwdParams& p, const float* __restrict__ E, size_t zbase, int64_t tok0,
-                                         int code0, int kc, int tid, f32x4 (&er)[T2<KC>::E_CHUNKS], f32x4 (&zr)[T2<KC>::Z_CHUNKS]) {
-    constexpr int CH = T2<KC>::CH;
-#pragma unroll
-    for (int q = 0; q < T2<KC>::E_CHUNKS; ++q) {
-        const int L = q * T2_THREADS + tid;
-        const int r = L / CH, c = L % CH;
-        int code = code0 + r;
-        code = code < p.K ? code : p.K - 1;
-        er[q] = *reinterpret_cast<const f32x4*>(E + (size_t)code * p.D + kc * KC + c * 4);
-    }
-#pragma unroll
-    for (int q = 0; q < T2<KC>::Z_CHUNKS; ++q) {
-        const int L = q * T2_THREADS + tid;
-        const int r = L / CH, c = L % CH;
-        const int64_t tok = tok0 + r;
-        const int64_t tokc = tok < p.N ? tok : p.N - 1;                  // no branch around the load (see stage_issue)
-        const f32x4 zv = IO<DT>::load4(p.z, zbase + (size_t)tokc * p.D + kc * KC + c * 4);
-        zr[q] = zv * (tok < p.N ? 1.0f : 0.0f);
-    }
-}
-
-template <int KC>
-__device__ __forceinline__ void t2_commit(float* sb, int tid, const f32x4 (&er)[T2<KC>::E_CHUNKS], const f32x4 (&zr)[T2<KC>::Z_CHUNKS]) {
-    constexpr int CH = T2<KC>::CH;
-#pragma unroll
-    for (int q = 0; q < T2<KC>::E_CHUNKS; ++q) {
-        const int L = q * T2_THREADS + tid;
-        const int r = L / CH, c = L % CH;
-        *reinterpret_cast<f32x4*>(sb + r * KC + ((c ^ T2<KC>::swz(r)) << 2)) = er[q];
-    }
-#pragma unroll
-    for (int q = 0; q < T2<KC>::Z_CHUNKS; ++q) {
-        const int L = q * T2_THREADS + tid;
-        const int r = L / CH, c = L % CH;
-        *reinterpret_cast<f32x4*>(sb + T2<KC>::E_TILE + r * KC + ((c ^ T2<KC>::swz(r)) << 2)) = zr[q];
-    }
-}
-
-template <int DT, int KC, bool PRIO>
-__global__ __launch_bounds__(T2_THREADS, T2<KC>::WGS_PER_CU) void vq_dist_tile_kernel(FwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int w = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
-    const int g = blockIdx.z;
-    const int64_t tok0 = (int64_t)blockIdx.x * T2_TM;
-    const int code0 = blockIdx.y * T2_CN;
-    const float* __restrict__ E = p.E + (size_t)g * p.K * p.D;
-    const size_t zbase = (size_t)g * p.N * p.D;
-    const int nst = p.D / KC;
-    constexpr int STAGE = T2<KC>::STAGE;
-
-    f32x4 er[T2<KC>::E_CHUNKS];
-    f32x4 zr[T2<KC>::Z_CHUNKS];
-    t2_issue<DT, KC>(p, E, zbase, tok0, code0, 0, tid, er, zr);
-    t2_commit<KC>(smem, tid, er, zr);
-    __syncthreads();
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float pe = 0.f, pz = 0.f;
-    const int sw = T2<KC>::swz(i);
-
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        const bool more = st + 1 < nst;
-        if (more) t2_issue<DT, KC>(p, E, zbase, tok0, code0, st + 1, tid, er, zr);
-        const float* sb = smem + buf * STAGE;
-        const float* erow = sb + (w * 32 + i) * KC;
-        const float* zrow = sb + T2<KC>::E_TILE + i * KC;
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int gq = 0; gq < KC / 8; ++gq) {
-            const int slot = ((2 * gq + h) ^ sw) << 2;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(erow + slot);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(zrow + slot);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-            pe = __builtin_fmaf(a.x, a.x, pe); pe = __builtin_fmaf(a.y, a.y, pe);
-            pe = __builtin_fmaf(a.z, a.z, pe); pe = __builtin_fmaf(a.w, a.w, pe);
-            pz = __builtin_fmaf(b.x, b.x, pz); pz = __builtin_fmaf(b.y, b.y, pz);
-            pz = __builtin_fmaf(b.z, b.z, pz); pz = __builtin_fmaf(b.w, b.w, pz);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (more) t2_commit<KC>(smem + (buf ^ 1) * STAGE, tid, er, zr);
-        __syncthreads();
-    }
-
-    // distances of this wave's 32 codes x 32 tokens; lane-local minimum over its 16 codes
-    const float z2 = pz + __shfl_xor(pz, 32, WAVE);
-    const float e2v = pe + __shfl_xor(pe, 32, WAVE);
-    const int cbase = code0 + w * 32;
-    float best = INFINITY;
-    int bidx = INT_MAX;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float e2r = __shfl(e2v, cl, WAVE);
-        const float t = z2 + e2r;
-        const float dd = t - 2.0f * acc[r];
-        const int code = cbase + cl;
-        if (code < p.K) {
-            if (p.dump && tok0 + i < p.N) p.dump[(size_t)(tok0 + i) * p.K + code] = dd;
-            if (cand_better(dd, code, best, bidx)) { best = dd; bidx = code; }
-        }
-    }
-    {
-        const float ob = __shfl_xor(best, 32, WAVE);
-        const int oi = __shfl_xor(bidx, 32, WAVE);
-        if (cand_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
-    }
-    // the stage buffers are dead (every wave passed the loop's last barrier): reuse them for the 4-wave merge
-    float* red_val = smem;
-    int* red_idx = reinterpret_cast<int*>(smem + T2_WAVES * T2_TM);
-    if (lane < 32) {
-        red_val[w * T2_TM + i] = best;
-        red_idx[w * T2_TM + i] = bidx;
-    }
-    __syncthreads();
-    if (tid < T2_TM && tok0 + tid < p.N) {
-        float b = red_val[tid];
-        int bi = red_idx[tid];
-#pragma unroll
-        for (int ww = 1; ww < T2_WAVES; ++ww) {
-            const float v = red_val[ww * T2_TM + tid];
-            const int vi = red_idx[ww * T2_TM + tid];
-            if (cand_better(v, vi, b, bi)) { b = v; bi = vi; }
-        }
-        if (bi != INT_MAX) atomicMin(p.keys + (size_t)g * p.N + tok0 + tid, pack_key(b, bi));
-    }
-}
-
-// ---- v3: codebook pre-packed in MFMA-fragment order -----------------------------------------------------------
+// ---- codebook pre-packed in MFMA-fragment order -----------------------------------------------------------
 // The A operand (32 codes x 8 contraction floats per MFMA group) belongs to ONE wave, so staging it through LDS buys
-// nothing and costs the LDS write path.  A tiny kernel re-lays E once per call as
+// nothing and costs the LDS write path.  A tiny kernel re-lays E (once per codebook update) as
 //     Epack[code_block32][k_group8][lane = (code i, half h)][4 floats] = E[32*cb + i][8*g + 4*h .. +3]
 // so that each A fragment is ONE fully coalesced 1-KiB wave load straight into VGPRs (double-buffered in registers).
 // Only the shared 32-token tile still goes through LDS (8 KiB per workgroup).  Same arithmetic, same bits.
@@ -873,6 +530,52 @@ __global__ __launch_bounds__(SEG_THREADS) void vq_seg_sum_kernel(BwdParams p) {
     const float* e = p.E ? p.E + ((size_t)g * p.K + k) * p.D : nullptr;
     float* out = p.slab + (((size_t)g * p.T + t) * p.K + k) * p.D;
     const size_t zrow0 = ((size_t)g * p.N + (size_t)n0) * p.D;
+    if ((p.D & 7) == 0) {
+        // Vector walk: a row is D/8 chunks of 8 elements (one 16-byte load of bf16); the workgroup is cut into RG row groups of cw
+        // threads (cw = the power of two >= D/8) that take every RG-th list entry, four rows in flight per thread; the groups'
+        // sums are then added in group order.  Fixed visiting order: bitwise reproducible.  With the codes of a training run
+        // (a few long lists instead of many short ones) the scalar walk below was latency-bound: one 2-byte load per row and
+        // thread (42-119 us per call in the step trace of round 1).
+        __shared__ float red[8 * SEG_THREADS];
+        const int CH = p.D >> 3;
+        int cw = 8;
+        while (cw < CH) cw <<= 1;
+        const int RG = SEG_THREADS / cw, rg = tid / cw, c = tid - rg * cw;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c < CH) {
+            f32x8 ev;
+            ev.lo = 0.f; ev.hi = 0.f;
+            if (MODE == 0) ev = IO<KVQ_F32>::load8(e, (size_t)c * 8);
+            const float ef[8] = {ev.lo.x, ev.lo.y, ev.lo.z, ev.lo.w, ev.hi.x, ev.hi.y, ev.hi.z, ev.hi.w};
+            int i = rg;
+            for (; i + 3 * RG < cnt; i += 4 * RG) {
+                f32x8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = IO<DT>::load8(p.z, zrow0 + (size_t)list[i + u * RG] * p.D + (size_t)c * 8);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float vf[8] = {v[u].lo.x, v[u].lo.y, v[u].lo.z, v[u].lo.w, v[u].hi.x, v[u].hi.y, v[u].hi.z, v[u].hi.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += (MODE == 0) ? (ef[j] - vf[j]) : vf[j];
+                }
+            }
+            for (; i < cnt; i += RG) {
+                const f32x8 v = IO<DT>::load8(p.z, zrow0 + (size_t)list[i] * p.D + (size_t)c * 8);
+                const float vf[8] = {v.lo.x, v.lo.y, v.lo.z, v.lo.w, v.hi.x, v.hi.y, v.hi.z, v.hi.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (MODE == 0) ? (ef[j] - vf[j]) : vf[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(size_t)rg * p.D + c * 8 + j] = acc[j];
+        }
+        __syncthreads();
+        for (int j = tid; j < p.D; j += SEG_THREADS) {
+            float a = 0.f;
+            for (int q = 0; q < RG; ++q) a += red[(size_t)q * p.D + j];
+            out[j] = a;
+        }
+        return;
+    }
     for (int j = tid; j < p.D; j += SEG_THREADS) {
         const float ej = (MODE == 0) ? e[j] : 0.f;
         float acc = 0.f;
@@ -1015,82 +718,38 @@ static WsLayout ws_layout(int64_t N, int K, int D, int G) {
 }
 
 static bool mfma_ok(int64_t N, int K, int D) { return N > 0 && K > 0 && D > 0 && D % 32 == 0; }
-static int g_fwd_variant = 2;
-static int g_t2_kc = 32, g_t2_prio = 1, g_t2_packed = 1, g_t2_tt = 2;   // tuning knobs of the tiled kernel (kvq_vq_set_tuning)   // 2 = tiled distance kernel + epilogue kernel; 1 = single fused kernel (needs D % 64 == 0)
 
+static void launch_pack(const float* E, int K, int D, int G, float* epack, hipStream_t st) {
+    const int64_t slots = (int64_t)((K + 31) / 32) * (D / 8) * 64;
+    const unsigned pb = (unsigned)((slots + 255) / 256 > 2048 ? 2048 : (slots + 255) / 256);
+    hipLaunchKernelGGL(vq_pack_codebook_kernel, dim3(pb, (unsigned)G), dim3(256), 0, st, E, K, D, epack);
+}
+
+// distances + arg-min + epilogue (everything of the forward except the final scalar reduction); `packed`: p.epack already
+// holds the fragment-ordered codebook (kvq_vq_pack_codebook)
 template <int DT>
-static int launch_forward(FwdParams p, int G, bool use_mfma, hipStream_t st) {
-    if (use_mfma && (g_fwd_variant == 2 || p.D % KC != 0)) {
+static int launch_forward(FwdParams p, int G, bool use_mfma, bool packed, hipStream_t st) {
+    if (use_mfma) {
         hipError_t e = hipMemsetAsync(p.keys, 0xff, (size_t)G * p.N * sizeof(unsigned long long), st);
         if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipMemsetAsync(keys): %s", hipGetErrorString(e));
-        dim3 grid((unsigned)((p.N + T2_TM - 1) / T2_TM), (unsigned)((p.K + T2_CN - 1) / T2_CN), (unsigned)G);
-        if (g_t2_packed) {
-            const int64_t slots = (int64_t)((p.K + 31) / 32) * (p.D / 8) * 64;
-            unsigned pb = (unsigned)((slots + 255) / 256 > 2048 ? 2048 : (slots + 255) / 256);
-            hipLaunchKernelGGL(vq_pack_codebook_kernel, dim3(pb, (unsigned)G), dim3(256), 0, st, p.E, p.K, p.D, const_cast<float*>(p.epack));
-            const bool prof = prof_begin(st);
-            if (g_t2_tt == 2) {
-                dim3 grid2((unsigned)((p.N + 63) / 64), grid.y, grid.z);
-                const size_t lds = 2 * 64 * T3_KC * sizeof(float);
-                if (p.D == 768) hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 24>), grid2, dim3(T2_THREADS), lds, st, p);
-                else hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 0>), grid2, dim3(T2_THREADS), lds, st, p);
-            } else {
-                const size_t lds = 2 * 32 * T3_KC * sizeof(float);
-                if (p.D == 768) hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 1, 24>), grid, dim3(T2_THREADS), lds, st, p);
-                else hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 1, 0>), grid, dim3(T2_THREADS), lds, st, p);
-            }
-            if (prof) prof_end(st);
-            int rc = check_launch("vq_dist_packed_kernel");
-            if (rc) return rc;
-            dim3 egrid((unsigned)((p.N + EP_TOK - 1) / EP_TOK), (unsigned)G);
-            hipLaunchKernelGGL(vq_epilogue_kernel<DT>, egrid, dim3(EP_THREADS), 0, st, p);
-            return check_launch("vq_epilogue_kernel");
-        }
-        const bool kc64 = g_t2_kc == 64 && p.D % 64 == 0;
-        if (kc64) {
-            static bool attr_done[2][2] = {{false, false}, {false, false}};
-            if (!attr_done[DT][g_t2_prio]) {
-                const void* fn = g_t2_prio ? reinterpret_cast<const void*>(&vq_dist_tile_kernel<DT, 64, true>)
-                                           : reinterpret_cast<const void*>(&vq_dist_tile_kernel<DT, 64, false>);
-                hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T2<64>::LDS_BYTES);
-                if (ea != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(ea));
-                attr_done[DT][g_t2_prio] = true;
-            }
-        }
+        if (!packed) launch_pack(p.E, p.K, p.D, G, const_cast<float*>(p.epack), st);
         const bool prof = prof_begin(st);
-        if (kc64) {
-            if (g_t2_prio) hipLaunchKernelGGL((vq_dist_tile_kernel<DT, 64, true>), grid, dim3(T2_THREADS), T2<64>::LDS_BYTES, st, p);
-            else hipLaunchKernelGGL((vq_dist_tile_kernel<DT, 64, false>), grid, dim3(T2_THREADS), T2<64>::LDS_BYTES, st, p);
-        } else {
-            if (g_t2_prio) hipLaunchKernelGGL((vq_dist_tile_kernel<DT, 32, true>), grid, dim3(T2_THREADS), T2<32>::LDS_BYTES, st, p);
-            else hipLaunchKernelGGL((vq_dist_tile_kernel<DT, 32, false>), grid, dim3(T2_THREADS), T2<32>::LDS_BYTES, st, p);
-        }
+        dim3 grid((unsigned)((p.N + 63) / 64), (unsigned)((p.K + T2_CN - 1) / T2_CN), (unsigned)G);
+        const size_t lds = 2 * 64 * T3_KC * sizeof(float);
+        if (p.D == 768) hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 24>), grid, dim3(T2_THREADS), lds, st, p);
+        else hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 0>), grid, dim3(T2_THREADS), lds, st, p);
         if (prof) prof_end(st);
-        int rc = check_launch("vq_dist_tile_kernel");
+        int rc = check_launch("vq_dist_packed_kernel");
         if (rc) return rc;
         dim3 egrid((unsigned)((p.N + EP_TOK - 1) / EP_TOK), (unsigned)G);
         hipLaunchKernelGGL(vq_epilogue_kernel<DT>, egrid, dim3(EP_THREADS), 0, st, p);
         return check_launch("vq_epilogue_kernel");
     }
-    if (use_mfma) {
-        static bool attr_done[2] = {false, false};
-        if (!attr_done[DT]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_fwd_mfma_kernel<DT>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-            if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", LDS_BYTES, hipGetErrorString(e));
-            attr_done[DT] = true;
-        }
-        dim3 grid((unsigned)((p.N + TM - 1) / TM), (unsigned)G);
-        const bool prof = prof_begin(st);
-        hipLaunchKernelGGL(vq_fwd_mfma_kernel<DT>, grid, dim3(NTHREADS), LDS_BYTES, st, p);
-        if (prof) prof_end(st);
-        return check_launch("vq_fwd_mfma_kernel");
-    }
     const int64_t rows = (int64_t)G * p.K;
     hipLaunchKernelGGL(row_sq_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p.E, rows, p.D,
                        const_cast<float*>(p.e2));
     const size_t lds = (size_t)GEN_WAVES * ((p.D + 7) & ~7) * sizeof(float);
-    if (lds > 64 * 1024) return fail(KVQ_E_INVALID, "generic path: D=%d too large (needs D %% 64 == 0 above 4096)", p.D);
+    if (lds > 64 * 1024) return fail(KVQ_E_INVALID, "generic path: D=%d too large (needs D %% 32 == 0 above 4096)", p.D);
     dim3 grid((unsigned)((p.N + GEN_WAVES - 1) / GEN_WAVES), (unsigned)G);
     hipLaunchKernelGGL(vq_fwd_generic_kernel<DT>, grid, dim3(GEN_WAVES * WAVE), lds, st, p);
     return check_launch("vq_fwd_generic_kernel");
@@ -1109,47 +768,32 @@ size_t kvq_vq_workspace_bytes(int64_t N, int K, int D, int G) {
 
 int kvq_vq_uses_mfma(int64_t N, int K, int D) { return mfma_ok(N, K, D) ? 1 : 0; }
 
-int kvq_vq_debug_occupancy(int* blocks_per_cu_tiled, int* blocks_per_cu_fused) {
-    int a = -1, b = -1;
-    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&vq_dist_tile_kernel<KVQ_BF16, 32, false>),
-                                                                 T2_THREADS, T2<32>::LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_fwd_mfma_kernel<KVQ_BF16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&vq_fwd_mfma_kernel<KVQ_BF16>),
-                                                                 NTHREADS, LDS_BYTES);
-    if (e1 != hipSuccess || e2 != hipSuccess) return fail(KVQ_E_LAUNCH, "occupancy query failed");
-    if (blocks_per_cu_tiled) *blocks_per_cu_tiled = a;
-    if (blocks_per_cu_fused) *blocks_per_cu_fused = b;
-    return KVQ_OK;
+size_t kvq_vq_packed_bytes(int K, int D, int G) {
+    return (size_t)G * ((K + 31) / 32) * 32 * D * sizeof(float);
 }
 
-int kvq_vq_set_tuning(int kc, int prio, int packed) {
-    if (kc != 32 && kc != 64) return fail(KVQ_E_INVALID, "kvq_vq_set_tuning: kc must be 32 or 64");
-    g_t2_kc = kc;
-    g_t2_prio = prio ? 1 : 0;
-    g_t2_packed = packed ? (packed >= 2 ? 2 : 1) : 0;   // packed: 0 = off, 1 = one 32-token tile per wave, 2 = two
-    g_t2_tt = packed >= 2 ? 2 : 1;
-    return KVQ_OK;
+int kvq_vq_pack_codebook(const float* E, int K, int D, int G, float* packed, void* stream) {
+    KVQ_REQUIRE(E && packed && K > 0 && D > 0 && G > 0, "kvq_vq_pack_codebook: bad argument");
+    KVQ_REQUIRE(D % 32 == 0, "kvq_vq_pack_codebook: the fragment-ordered copy exists for D %% 32 == 0 only (got %d)", D);
+    KVQ_REQUIRE((((uintptr_t)E | (uintptr_t)packed) & 15) == 0, "kvq_vq_pack_codebook: E and packed must be 16-byte aligned");
+    launch_pack(E, K, D, G, packed, (hipStream_t)stream);
+    return check_launch("vq_pack_codebook_kernel");
 }
 
-int kvq_vq_set_forward_variant(int variant) {
-    if (variant != 1 && variant != 2) return fail(KVQ_E_INVALID, "kvq_vq_set_forward_variant: 1 or 2, got %d", variant);
-    g_fwd_variant = variant;
-    return KVQ_OK;
-}
-
-int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G, int io_dtype, float beta,
-                   void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts, void* ws,
-                   size_t ws_bytes, void* stream) {
+static int vq_forward_impl(const void* z, const float* E, const float* packed, int64_t N, int K, int D, int G, int io_dtype, float beta,
+                           void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts, void* ws,
+                           size_t ws_bytes, void* stream) {
     KVQ_REQUIRE(z && E && z_q && idx && loss && perplexity, "kvq_vq_forward: null pointer argument");
     KVQ_REQUIRE(N > 0 && K > 0 && D > 0 && G > 0, "kvq_vq_forward: N=%lld K=%d D=%d G=%d must be positive", (long long)N, K, D, G);
     KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "kvq_vq_forward: unsupported io dtype %d", io_dtype);
-    KVQ_REQUIRE(N < (1ll << 31) * TM, "kvq_vq_forward: N too large");
+    KVQ_REQUIRE(N < (1ll << 36), "kvq_vq_forward: N too large");
     const WsLayout l = ws_layout(N, K, D, G);
     if (!ws || ws_bytes < l.total) return fail(KVQ_E_WORKSPACE, "kvq_vq_forward: workspace %zu < %zu bytes", ws_bytes, l.total);
     KVQ_REQUIRE(((uintptr_t)ws & 255) == 0, "kvq_vq_forward: workspace must be 256-byte aligned");
     KVQ_REQUIRE(((uintptr_t)z & 15) == 0 && ((uintptr_t)E & 15) == 0 && ((uintptr_t)z_q & 15) == 0,
                 "kvq_vq_forward: z, E, z_q must be 16-byte aligned");
+    const bool fast = mfma_ok(N, K, D);
+    KVQ_REQUIRE(!packed || (fast && ((uintptr_t)packed & 15) == 0), "kvq_vq_forward_packed: needs D %% 32 == 0 and a 16-byte aligned copy");
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
     FwdParams p;
@@ -1158,17 +802,30 @@ int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G
     p.counts = (unsigned*)(w + l.counts);
     p.e2 = (const float*)(w + l.e2);
     p.keys = (unsigned long long*)(w + l.keys);
-    p.epack = (const float*)(w + l.epack);
+    p.epack = packed ? packed : (const float*)(w + l.epack);
     p.dump = nullptr;
     p.N = N; p.K = K; p.D = D;
     hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)G * K * sizeof(unsigned), st);
     if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
-    const bool fast = mfma_ok(N, K, D);
-    int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, G, fast, st) : launch_forward<KVQ_BF16>(p, G, fast, st);
+    int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, G, fast, packed != nullptr, st)
+                                 : launch_forward<KVQ_BF16>(p, G, fast, packed != nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)G), dim3(FIN_THREADS), 0, st, p.tok_sumsq, p.counts, N, K, D,
                        beta, loss, perplexity, counts);
     return check_launch("vq_finalize_kernel");
+}
+
+int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G, int io_dtype, float beta,
+                   void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts, void* ws,
+                   size_t ws_bytes, void* stream) {
+    return vq_forward_impl(z, E, nullptr, N, K, D, G, io_dtype, beta, z_q, idx, loss, perplexity, counts, ws, ws_bytes, stream);
+}
+
+int kvq_vq_forward_packed(const void* z, const float* E, const float* packed, int64_t N, int K, int D, int G, int io_dtype,
+                          float beta, void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts, void* ws,
+                          size_t ws_bytes, void* stream) {
+    KVQ_REQUIRE(packed, "kvq_vq_forward_packed: null packed codebook");
+    return vq_forward_impl(z, E, packed, N, K, D, G, io_dtype, beta, z_q, idx, loss, perplexity, counts, ws, ws_bytes, stream);
 }
 
 int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int D, int io_dtype, int use_mfma,
@@ -1192,8 +849,8 @@ int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int 
     p.epack = (const float*)(w + l.epack);
     p.dump = d; p.N = N; p.K = K; p.D = D;
     (void)hipMemsetAsync(p.counts, 0, (size_t)K * sizeof(unsigned), st);
-    int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, 1, use_mfma != 0, st)
-                                 : launch_forward<KVQ_BF16>(p, 1, use_mfma != 0, st);
+    int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, 1, use_mfma != 0, false, st)
+                                 : launch_forward<KVQ_BF16>(p, 1, use_mfma != 0, false, st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(w); (void)hipFree(zq); (void)hipFree(ix);
     return rc;

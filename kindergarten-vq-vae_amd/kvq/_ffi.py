@@ -41,11 +41,11 @@ SIGNATURES = {
     "kvq_prof_enable": (_int, [_int]),
     "kvq_prof_read": (_int, [C.POINTER(C.c_float), _int]),
     "kvq_vq_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
-    "kvq_vq_set_forward_variant": (_int, [_int]),
-    "kvq_vq_set_tuning": (_int, [_int, _int, _int]),
-    "kvq_vq_debug_occupancy": (_int, [C.POINTER(_int), C.POINTER(_int)]),
     "kvq_vq_uses_mfma": (_int, [_i64, _int, _int]),
     "kvq_vq_forward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kvq_vq_packed_bytes": (_sz, [_int, _int, _int]),
+    "kvq_vq_pack_codebook": (_int, [_vp, _int, _int, _int, _vp, _vp]),
+    "kvq_vq_forward_packed": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "kvq_vq_backward": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _sz, _vp]),
     "kvq_vq_one_hot": (_int, [_vp, _i64, _int, _vp, _vp]),
     "kvq_vq_debug_distances": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),

@@ -371,6 +371,11 @@ class TrainEngine:
             self.beta_vq = float(vq.beta)
             self.vq_ema = getattr(vq, "ema_decay", None) is not None     # extension: EMA codebook update instead of the gradient
             self.gE = add_aux(self.E) if self.E.requires_grad else torch.zeros_like(self.E.data)
+            # the codebook in MFMA-fragment order (kvq_vq_pack_codebook): rebuilt after every codebook update -- Adam at the end
+            # of the step, the EMA step, or a write from outside (noticed through the tensor version) -- not per forward call
+            self._epack = torch.empty(lib().kvq_vq_packed_bytes(self.K, self.Dg, self.G), dtype=torch.uint8, device=dev) \
+                if self.Dg % 32 == 0 else None
+            self._E_version = None
         elif self.vq_kind == "GumbelQuantizer":
             gq = model.vector_quantizer
             if gq.n_embed > 1024:
@@ -993,6 +998,24 @@ class TrainEngine:
             t = self._bufs[key] = torch.empty(shape, dtype=dtype, device=self.dev)
         return t
 
+    def _repack_codebook(self):
+        if self._epack is not None:
+            check(lib().kvq_vq_pack_codebook(self.E.data_ptr(), self.K, self.Dg, self.G, self._epack.data_ptr(), stream_ptr()),
+                  "kvq_vq_pack_codebook")
+            self._E_version = self.E._version
+
+    def _vq_fwd_call(self, z, N, D, G, z_q, idx, loss, perp, ws):
+        if self._epack is None:
+            check(lib().kvq_vq_forward(z.data_ptr(), self.E.data_ptr(), N, self.K, D, G, self.io, self.beta_vq, z_q.data_ptr(),
+                                       idx.data_ptr(), loss.data_ptr(), perp.data_ptr(), None, ws.data_ptr(), ws.numel(), stream_ptr()),
+                  "kvq_vq_forward")
+            return
+        if self.E._version != self._E_version:          # first call, or the codebook was written from outside the engine
+            self._repack_codebook()
+        check(lib().kvq_vq_forward_packed(z.data_ptr(), self.E.data_ptr(), self._epack.data_ptr(), N, self.K, D, G, self.io,
+                                          self.beta_vq, z_q.data_ptr(), idx.data_ptr(), loss.data_ptr(), perp.data_ptr(), None,
+                                          ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward_packed")
+
     def _vq_forward(self, z, z_q, idx, vq_out):
         """kvq_vq_forward on the encoder output: one codebook (the reference's VectorQuantizer), or G codebooks on G column
         slices as one grouped launch (MultiVectorQuantizer: loss / perplexity = mean over the factors)."""
@@ -1000,18 +1023,14 @@ class TrainEngine:
         G, K, Dg = self.G, self.K, self.Dg
         ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, K, Dg, G))
         if G == 1:
-            check(lib().kvq_vq_forward(z.data_ptr(), self.E.data_ptr(), N, K, H, 1, self.io, self.beta_vq,
-                                       z_q.data_ptr(), idx.data_ptr(), vq_out[0:].data_ptr(), vq_out[1:].data_ptr(), None,
-                                       ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward")
+            self._vq_fwd_call(z, N, H, 1, z_q, idx, vq_out[0:], vq_out[1:], ws)
             zsrc = z
         else:
             zg = self._buf("zg", (G, N, Dg), z.dtype)
             zg.copy_(z.view(N, G, Dg).permute(1, 0, 2))
             zqg = self._buf("zqg", (G, N, Dg), z.dtype)
             lp = self._buf("lp", (2, G), torch.float32)
-            check(lib().kvq_vq_forward(zg.data_ptr(), self.E.data_ptr(), N, K, Dg, G, self.io, self.beta_vq,
-                                       zqg.data_ptr(), idx.data_ptr(), lp[0].data_ptr(), lp[1].data_ptr(), None,
-                                       ws.data_ptr(), ws.numel(), stream_ptr()), "kvq_vq_forward")
+            self._vq_fwd_call(zg, N, Dg, G, zqg, idx, lp[0], lp[1], ws)
             z_q.view(N, G, Dg).copy_(zqg.permute(1, 0, 2))
             vq_out.copy_(lp.mean(1))
             zsrc = zg
@@ -1046,6 +1065,7 @@ class TrainEngine:
         zs, zdt, ishape = self._ema_shapes
         z, idx = self._buf("ema_z", zs, zdt), self._buf("ema_idx", ishape, torch.int64)
         self.model.vector_quantizer.ema_update(z, idx.view(self.G, -1) if self.G > 1 else idx)
+        self._repack_codebook()
 
     # ---- GumbelQuantizer (models/shelgon3/GumbelQuantizer.py:43-83): 1x1 conv = GEMM, row kernel, codebook GEMM ----------------
     def _gumbel_forward(self, z, training):
@@ -1116,6 +1136,8 @@ class TrainEngine:
             if a["p"].requires_grad:
                 nnops.adam_step_dev(a["p"].data.view(-1), a["g"].view(-1), a["m"].view(-1), a["v"].view(-1), self._state,
                                     b1, b2, self.eps, self.wd, vmax=a["vmax"].view(-1) if a["vmax"] is not None else None)
+        if self.vq_kind in ("VectorQuantizer", "MultiVectorQuantizer") and self.E.requires_grad:
+            self._repack_codebook()
 
 
     def _versions(self):

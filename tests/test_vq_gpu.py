@@ -84,21 +84,38 @@ def test_backward_vs_oracle_and_reference(kvq, name):
     assert not got["grad_E"][unused].any()
 
 
-@pytest.fixture(params=["packed2", "packed", "tiled", "tiled64", "fused"])
+@pytest.fixture(params=["per_call_pack", "prepacked"])
 def variant(request, kvq):
-    """Every MFMA forward structure (include/kvq.h kvq_vq_set_forward_variant / kvq_vq_set_tuning) must give identical bits."""
+    """The two entry points of the MFMA forward (kvq_vq_forward packs the codebook itself, kvq_vq_forward_packed takes the copy
+    kvq_vq_pack_codebook made) must give identical bits."""
+    return request.param
+
+
+def _run_fwd(kvq, z, E, beta, variant):
+    if variant == "per_call_pack":
+        return _run(kvq, z, E, beta)
+    import torch
+    from kvq._ffi import check
+    from kvq.functional import _workspace
     lib = kvq._ffi.lib()
-    fv, kc, packed = {"packed2": (2, 32, 2), "packed": (2, 32, 1), "tiled": (2, 32, 0), "tiled64": (2, 64, 0), "fused": (1, 32, 0)}[request.param]
-    assert lib.kvq_vq_set_forward_variant(fv) == 0 and lib.kvq_vq_set_tuning(kc, 1, packed) == 0
-    yield request.param
-    lib.kvq_vq_set_forward_variant(2)
-    lib.kvq_vq_set_tuning(32, 1, 2)
+    zt, Et = _dev(z.reshape(-1, z.shape[-1])), _dev(E)
+    N, D = zt.shape
+    K = Et.shape[0]
+    pk = torch.empty(lib.kvq_vq_packed_bytes(K, D, 1), dtype=torch.uint8, device="cuda")
+    check(lib.kvq_vq_pack_codebook(Et.data_ptr(), K, D, 1, pk.data_ptr(), None), "pack")
+    z_q = torch.empty_like(zt); idx = torch.empty(N, dtype=torch.int64, device="cuda")
+    out = torch.empty(2, dtype=torch.float32, device="cuda"); cnt = torch.empty(K, dtype=torch.float32, device="cuda")
+    ws = _workspace(zt.device, lib.kvq_vq_workspace_bytes(N, K, D, 1))
+    check(lib.kvq_vq_forward_packed(zt.data_ptr(), Et.data_ptr(), pk.data_ptr(), N, K, D, 1, 0, float(beta), z_q.data_ptr(), idx.data_ptr(),
+                                    out[0:].data_ptr(), out[1:].data_ptr(), cnt.data_ptr(), ws.data_ptr(), ws.numel(), None), "fwd")
+    torch.cuda.synchronize()
+    return dict(idx=idx.cpu().numpy(), z_q=z_q.cpu().numpy(), counts=cnt.cpu().numpy(), loss=out[0].item(), perplexity=out[1].item())
 
 
 @pytest.mark.parametrize("name", ["c1_sep", "c1_default", "k8192_sep", "demo_default"])
 def test_forward_both_variants_vs_oracle(kvq, variant, name):
     c = load_case(name)
-    got = _run(kvq, c["z"], c["E"], float(c["beta"]))
+    got = _run_fwd(kvq, c["z"], c["E"], float(c["beta"]), variant)
     ora = O.vq_forward(c["z"], c["E"], float(c["beta"]))
     assert np.array_equal(got["idx"], ora["idx"]) and np.array_equal(got["z_q"], ora["z_q"].reshape(-1, c["D"]))
     assert np.array_equal(got["counts"], ora["counts"])
@@ -107,7 +124,7 @@ def test_forward_both_variants_vs_oracle(kvq, variant, name):
 
 @pytest.mark.parametrize("shape", [(64, 512, 768), (100, 300, 128), (33, 37, 64), (256, 8192, 64)])
 @pytest.mark.parametrize("regime", ["sep", "near_tie"])
-def test_mfma_distances_bitwise_equal_oracle(kvq, variant, shape, regime):
+def test_mfma_distances_bitwise_equal_oracle(kvq, shape, regime):
     """The f32 MFMA contraction must be the documented fmaf chain: distance matrices equal bit for bit."""
     N, K, D = shape
     rng = np.random.default_rng(N + K + D)

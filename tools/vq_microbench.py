@@ -39,10 +39,7 @@ def kernel_us(fn, iters=30):
 
 
 def run(tag, N, K, D, dt, z, E):
-    for variant in (1, 2):
-        _ffi.lib().kvq_vq_set_forward_variant(variant)
-        run1(f"{tag}/v{variant}", N, K, D, dt, z, E)
-    _ffi.lib().kvq_vq_set_forward_variant(2)
+    run1(tag, N, K, D, dt, z, E)
 
 
 def run1(tag, N, K, D, dt, z, E):
