@@ -24,6 +24,8 @@
 //   * tiles are numbered so that each XCD (private L2) owns a contiguous band of tiles.
 //   * a launch can cover several problems of one layout ("grouped"): the weight gradients of one transformer layer are ONE
 //     launch of ~250 tiles of 128 x 256 -- one tile per CU over the whole 8192-token contraction, no split-K, no partial slabs.
+#include <stdlib.h>
+
 #include "kvq_common.h"
 
 namespace kvq {
@@ -48,6 +50,7 @@ struct Problem {
     int lda, ldb, ldc;
     int tiles_m, tiles_n;
     int tile0;                         // first tile id of this problem in the launch
+    int band;                          // tile rows per band: inside a band tiles are numbered row-fastest (see the kernel)
     int accumulate;                    // C += result
     unsigned short* C2;                // EPI_GELU: second output gelu(C)
     const unsigned short* H;           // EPI_DGELU: pre-activation h [M, N] (row stride ldc); C = (A.B) * gelu'(h)
@@ -288,8 +291,15 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
     for (int i = 1; i < MAX_PROBLEMS; ++i)
         if (i < P.nprob && id >= P.p[i].tile0) pi = i;
     const Problem& pr = P.p[pi];
+    // Tile order inside the problem: bands of `band` tile rows, row-fastest inside a band: the tiles an XCD runs together share
+    // `band` A tile rows (resident in its 4 MiB L2) and each B tile is fetched once per band instead of once per tile row
+    // (fabric traffic per shape: profiles/r02_gemm_pmc.md).  band = 1: column-fastest.
     const int lt = id - pr.tile0;
-    const int tm = lt / pr.tiles_n, tn = lt - tm * pr.tiles_n;
+    const int per_band = pr.band * pr.tiles_n;
+    const int bnd = lt / per_band, inb = lt - bnd * per_band;
+    const int r0 = bnd * pr.band;
+    const int rb = pr.tiles_m - r0 < pr.band ? pr.tiles_m - r0 : pr.band;
+    const int tn = inb / rb, tm = r0 + inb - tn * rb;
     const int m0 = tm * C::BM, n0 = tn * C::BN;
     const int nkt = pr.K / BK;
 
@@ -520,6 +530,11 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
         d.M = q.M; d.N = q.N; d.K = q.K; d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc;
         d.tiles_m = (q.M + bm - 1) / bm; d.tiles_n = (q.N + bn - 1) / bn;
         d.tile0 = t0; d.accumulate = q.accumulate;
+        // wide outputs: bands of two tile rows (measured on MI355X, tools/gemm2_probe_big.py: LM head 256x256 387 -> 370 us, cross-K/V
+        // 238 -> 222 us; taller bands lose again -- the C rows written together get shorter); a few tile columns: column-fastest
+        d.band = d.tiles_n >= 8 ? 2 : 1;
+        if (getenv("KVQ_GEMM_BAND")) d.band = atoi(getenv("KVQ_GEMM_BAND")) > 0 ? atoi(getenv("KVQ_GEMM_BAND")) : d.band;
+        if (d.band > d.tiles_m) d.band = d.tiles_m;
         d.C2 = nullptr; d.H = nullptr; d.part = nullptr;
         t0 += d.tiles_m * d.tiles_n;
     }

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Every GEMM shape of the benchmarked step, own kernel (csrc/kvq_gemm2.hip) and vendor library, a few launches each with a
+marker kernel in between -- the workload of the rocprofv3 --pmc passes behind profiles/r02_gemm_pmc.md
+(tools/run_gemm_pmc.sh; summary: tools/make_gemm_pmc_summary.py)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+import torch  # noqa: E402
+from kvq import nnops  # noqa: E402
+
+T, REP = 8192, 4
+dev = "cuda"
+rnd = lambda *s: torch.randn(s, device=dev).to(torch.bfloat16)  # noqa: E731
+marker = torch.zeros(64, device=dev, dtype=torch.int32)
+plan = []
+
+
+def mark(label):
+    plan.append(label)
+    marker.fill_(len(plan))          # one elementwise fill kernel = separator in the dispatch trace
+
+
+def both(label, layout, M, N, K, tile):
+    if layout == "nt":
+        a, b = rnd(M, K), rnd(N, K); lib = lambda: torch.mm(a, b.t())  # noqa: E702,E731
+    elif layout == "nn":
+        a, b = rnd(M, K), rnd(K, N); lib = lambda: torch.mm(a, b)  # noqa: E702,E731
+    else:
+        a, b = rnd(K, M), rnd(K, N); lib = lambda: torch.mm(a.t(), b)  # noqa: E702,E731
+    out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    for who, fn in (("own " + tile, lambda: nnops.gemm(a, b, layout, out=out, tile=tile)), ("lib", lib)):
+        fn(); torch.cuda.synchronize()
+        mark(dict(label=label, who=who, layout=layout, M=M, N=N, K=K, flops=2.0 * M * N * K,
+                  alg_bytes=2 * (M * K + N * K + M * N)))
+        for _ in range(REP):
+            fn()
+    torch.cuda.synchronize()
+
+
+for n, k, t in [(768, 768, "128x256"), (2304, 768, "256x192"), (3072, 768, "256x192"), (768, 3072, "128x256"), (18432, 768, "256x256"),
+                (30528, 768, "256x256")]:
+    both("fwd", "nt", T, n, k, t)
+for n, k, t in [(768, 768, "128x256"), (768, 2304, "128x256"), (768, 3072, "128x256"), (3072, 768, "256x192"), (768, 18432, "128x256"),
+                (768, 30528, "128x256")]:
+    both("dgrad", "nn", T, n, k, t)
+for m, n, t in [(768, 768, "128x256"), (2304, 768, "128x256"), (3072, 768, "128x256"), (768, 3072, "128x256"), (18432, 768, "256x256"),
+                (30528, 768, "256x192")]:
+    both("wgrad", "tn", m, n, T, t)
+# the per-layer grouped weight-gradient launch of the engine (encoder layer: QKV, O, FFN1, FFN2)
+shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+gys = [rnd(T, m) for m, _ in shapes]; xs = [rnd(T, n) for _, n in shapes]  # noqa: E702
+outs = [torch.empty((m, n), device=dev, dtype=torch.bfloat16) for m, n in shapes]
+probs = [nnops.gemm_problem(g, x, o, "tn") for g, x, o in zip(gys, xs, outs)]
+nnops.gemm_grouped(probs, "tn", "128x256"); torch.cuda.synchronize()  # noqa: E702
+mark(dict(label="wgrad-layer", who="own grouped 128x256", layout="tn", M=6912, N=0, K=T, flops=sum(2.0 * T * m * n for m, n in shapes),
+          alg_bytes=sum(2 * (T * m + T * n + m * n) for m, n in shapes)))
+for _ in range(REP):
+    nnops.gemm_grouped(probs, "tn", "128x256")
+torch.cuda.synchronize()
+mark(dict(label="end", who="", layout="", M=0, N=0, K=0, flops=0, alg_bytes=0))
+out_dir = os.environ.get("KVQ_PMC_PLAN_DIR", "gpurun_out")
+json.dump(plan, open(os.path.join(out_dir, "gemm_pmc_plan.json"), "w"))
