@@ -432,9 +432,12 @@ class TrainEngine:
     _OWN_DGELU = {}                                                             # (gy . W) * gelu'(h) + bias-gradient partials
     _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "256x192"}      # gW = gy^T . x          ("tn"), own launch
 
-    def _linear(self, x, wname, bname, fused=None):
-        W = self.flat.fused(fused[0], self.flat.shadow) if fused else self.flat.w(wname)
-        b = self.flat.fused(fused[1], self.flat.shadow) if fused else self.flat.w(bname)
+    def _linear(self, x, wname, bname, fused=None, Wb=None):
+        if Wb is not None:
+            W, b = Wb
+        else:
+            W = self.flat.fused(fused[0], self.flat.shadow) if fused else self.flat.w(wname)
+            b = self.flat.fused(fused[1], self.flat.shadow) if fused else self.flat.w(bname)
         if self._own_fwd and self.dtype == torch.bfloat16 and x.shape[0] >= 2048 and x.stride(1) == 1:
             tile = self._OWN_FWD.get(tuple(W.shape))
             if tile is not None:
@@ -884,7 +887,7 @@ class TrainEngine:
         dec_saved = []
         kv_all = None
         if self._cakv_batched:             # keys | values of every decoder layer's cross-attention in one [N, L*2H] GEMM
-            kv_all = torch.addmm(fl.fused(self._cakv_b, fl.shadow), enc_out, fl.fused(self._cakv_w, fl.shadow).t())
+            kv_all = self._linear(enc_out, None, None, Wb=(fl.fused(self._cakv_w, fl.shadow), fl.fused(self._cakv_b, fl.shadow)))
         for i in range(self.n_dec_layers):
             y, sa = self._attn_block_fwd(f"dec.{i}.sa.", y, None, d_mask, True, dcfg, training, B, Sd, Sd)
             y, ca = self._attn_block_fwd(f"dec.{i}.ca.", y, enc_out, None, False, dcfg, training, B, Sd, S,
@@ -895,7 +898,7 @@ class TrainEngine:
         hN, hpre, hmean, hrstd = nnops.ln_fwd(ta, None, fl.w32("head.ln.w"), fl.w32("head.ln.b"), dcfg.layer_norm_eps)
         Wv = fl.w("dec.emb.word", rows=self.Vp)                              # [Vp,H], rows >= V are zero
         bv = fl.shadow[fl.seg["head.bias"][0]: fl.seg["head.bias"][0] + self.Vp]
-        logits = torch.addmm(bv, hN, Wv.t())                                  # [N,Vp]
+        logits = self._linear(hN, None, None, Wb=(Wv, bv))                    # [N,Vp]
         tgt = d_ids.reshape(-1)
         row_loss = torch.empty(Nd, dtype=torch.float32, device=self.dev)
         row_lse = torch.empty(Nd, dtype=torch.float32, device=self.dev)
