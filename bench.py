@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--bucket-mib", type=int, default=64)
+    ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4]: forward GEMMs on the fp8 matrix cores (backward bf16)")
+    ap.add_argument("--factors", type=int, default=1, help="configs[4]: codebooks (MultiVectorQuantizer, K codes each); 1 = the reference's VectorQuantizer")
     ap.add_argument("--path", default="engine", choices=["engine", "autograd"],
                     help="engine = kvq.engine.TrainEngine (explicit fwd/bwd over flat buffers); autograd = kvq.bert + torch autograd")
     return ap.parse_args()
@@ -91,8 +93,12 @@ def main():
     torch.manual_seed(0)
     from models.bagon.Bagon import LOCAL_BERT_CONFIGS
     hidden = LOCAL_BERT_CONFIGS[a.model].get("hidden_size", 768)
-    vq = VectorQuantizer(n_e=a.codes, e_dim=hidden, beta=0.25)
-    vq.materialize_min_encodings = False
+    if a.factors > 1:
+        from models.shelgon3.MultiVectorQuantizer import MultiVectorQuantizer
+        vq = MultiVectorQuantizer(n_factors=a.factors, n_e=a.codes, e_dim=hidden, beta=0.25)
+    else:
+        vq = VectorQuantizer(n_e=a.codes, e_dim=hidden, beta=0.25)
+        vq.materialize_min_encodings = False
     model = Shelgon(a.model, vq, a.model, None, compute_dtype=dtype).to(dev)
     if model.encoder.config.hidden_size != vq.e_dim:
         raise SystemExit("model hidden size must equal the codebook dimension")
@@ -103,7 +109,7 @@ def main():
     if a.path == "engine":
         from kvq.engine import TrainEngine
         engine = TrainEngine(model, lr=1e-4, weight_decay=0.0, amsgrad=False, milestones=[10000, 20000], gamma=0.1,
-                             bucket_mib=a.bucket_mib)
+                             bucket_mib=a.bucket_mib, fp8_forward=a.fp8)
     else:
         params = [p for p in model.parameters() if p.requires_grad]
         opt = torch.optim.Adam(params, lr=1e-4, weight_decay=0.0, amsgrad=False, fused=True)
@@ -190,9 +196,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": f"Bagon VQ (Shelgon) {a.model} enc/dec, K={a.codes} D={D} seq_len={a.seq_len} "
-                                   f"batch={a.batch}/GPU, mode={a.mode}, Adam, dropout on, path={a.path}",
+            "dtype": ("fp8 forward GEMMs / bf16" if a.fp8 else "bf16") if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "config": {"workload": f"Bagon VQ (Shelgon) {a.model} enc/dec, {str(a.factors) + ' x ' if a.factors > 1 else ''}K={a.codes} D={D} "
+                                   f"seq_len={a.seq_len} batch={a.batch}/GPU, mode={a.mode}, Adam, dropout on, path={a.path}"
+                                   + (", fp8 forward GEMMs" if a.fp8 else ""),
                        "global_batch": world * a.batch, "seq_len": a.seq_len, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
             "graph": bool(engine is not None and engine._graphs),      # False = the step ran as ~800 eager launches (capture failed or off)

@@ -279,6 +279,27 @@ int64_t kvq_gemm_dgelu_partial_rows(int64_t M, int tile);
 int kvq_gemm_bf16_dgelu(const void* A, const void* B, const void* H, void* C, float* part, size_t part_bytes, int M, int N, int K,
                         int lda, int ldb, int ldc, int tile, void* stream);
 
+/* ---- fp8 (OCP e4m3fn) forward GEMMs: extension named by BASELINE.json configs[4]; the reference is f32 throughout -> off by default.
+ *   y = x . W^T + b of a BERT linear (modeling_bert.py:139-352) as  (sat(x sx) . sat(W sw)^T) / (sx sw) + b,  s = 448 / amax|.|
+ *   per tensor, computed in the same step from the tensor that is quantised (no amax history).  Backward stays bf16.
+ * kvq_fp8_quantize: one bf16 matrix [rows, cols] (row stride ld) -> dense fp8 [rows, cols]; amax, scale: device scalars (written).
+ * kvq_fp8_quantize_segments: ranges [seg_off[s], +seg_n[s]) (elements; device arrays; multiples of 16) of one bf16 buffer ->
+ *   the same ranges of an fp8 buffer, one amax / scale per range: all GEMM weights of the model in two launches.
+ * kvq_gemm_fp8_nt: C[M,N] bf16 = (A8[M,K] . B8[N,K]^T) / (scale_a[0] scale_b[0]) + bias;  K %% 128 == 0, lda, ldb %% 16 == 0
+ *   (fp8 elements), on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 matrix rate). */
+int kvq_fp8_quantize(const void* x_bf16, int64_t rows, int cols, int64_t ld, void* out_fp8, float* amax, float* scale, void* stream);
+/* Activations, one pass ("delayed scaling"): per call site a device record of kvq_fp8_state_floats() floats, [0] = scale
+ * (initialise to 1), the rest per-workgroup amax partials (initialise to 0): quantise with the site's scale and leave this
+ * tensor's amax in the partials; kvq_fp8_update_scales (once per step, nsites consecutive records) sets
+ * scale = 448 / (amax * headroom) and clears the partials.  Values beyond the previous step's range saturate at +-448. */
+int kvq_fp8_state_floats(void);
+int kvq_fp8_quantize_delayed(const void* x_bf16, int64_t rows, int cols, int64_t ld, void* out_fp8, float* state, void* stream);
+int kvq_fp8_update_scales(float* state, int nsites, float headroom, void* stream);
+int kvq_fp8_quantize_segments(const void* src_bf16, const int64_t* seg_off, const int64_t* seg_n, int nseg, int64_t max_seg_n,
+                              void* dst_fp8, float* amax, float* scale, void* stream);
+int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const float* scale_b, const void* bias, void* C, int M, int N,
+                    int K, int lda, int ldb, int ldc, void* stream);
+
 /* torch.optim.Adam step (models/shelgon3/main.py:91: lr, weight_decay (L2, coupled), amsgrad) on flat buffers.
  *   p, m, v [, vmax] f32; g grad_dtype (scaled by grad_scale first); shadow_bf16 (may be NULL) receives bf16(p_new).
  *   step >= 1 is the 1-based step count for bias correction.  n %% 4 == 0. */

@@ -55,6 +55,8 @@ struct Problem {
     unsigned short* C2;                // EPI_GELU: second output gelu(C)
     const unsigned short* H;           // EPI_DGELU: pre-activation h [M, N] (row stride ldc); C = (A.B) * gelu'(h)
     float* part;                       // EPI_DGELU: [tiles_m][N] f32 column sums of C over each tile's rows (bias-gradient partials)
+    const float* scaleA;               // fp8 kernel: per-tensor quantisation scales of the two operands (device scalars)
+    const float* scaleB;
 };
 
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2;
@@ -273,14 +275,13 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class C, int EPI>
-__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w / C::WN, wn = w % C::WN;
-
-    // ---- tile of this workgroup: XCD-aware numbering (bijective form), then problem lookup
+// ---- which tile does this workgroup own ------------------------------------------------------------------------------------
+struct TileId {
+    int pi, tm, tn, m0, n0;
+};
+template <class C>
+__device__ __forceinline__ TileId locate_tile(const Params& P) {
+    // XCD-aware numbering (bijective form), then problem lookup
     int id = blockIdx.x;
     {
         const int nt = P.ntiles, q = nt >> 3, r = nt & 7, x = id & 7;
@@ -299,75 +300,32 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
     const int bnd = lt / per_band, inb = lt - bnd * per_band;
     const int r0 = bnd * pr.band;
     const int rb = pr.tiles_m - r0 < pr.band ? pr.tiles_m - r0 : pr.band;
-    const int tn = inb / rb, tm = r0 + inb - tn * rb;
-    const int m0 = tm * C::BM, n0 = tn * C::BN;
-    const int nkt = pr.K / BK;
+    TileId t;
+    t.pi = pi;
+    t.tn = inb / rb;
+    t.tm = r0 + inb - t.tn * rb;
+    t.m0 = t.tm * C::BM;
+    t.n0 = t.tn * C::BN;
+    return t;
+}
 
-    f32x4 acc[C::FA][C::FB];
+// the bias values this lane will add in the epilogue: requested at kernel start, FB dependent round trips to L2 later otherwise
+template <class C>
+__device__ __forceinline__ void load_bias(const Problem& pr, int n0, int wn, int lane, u16x4 (&biasv)[C::FB]) {
+    const int fk0 = lane >> 4;
 #pragma unroll
-    for (int mi = 0; mi < C::FA; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < C::FB; ++ni) acc[mi][ni] = 0.f;
-
-    // the bias values this lane will add in the epilogue: requested now, FB dependent round trips to L2 later otherwise
-    u16x4 biasv[C::FB];
-    {
-        const int fk0 = lane >> 4;
-#pragma unroll
-        for (int ni = 0; ni < C::FB; ++ni) {
-            int nb = n0 + wn * C::TN + ni * 16 + 4 * fk0;
-            nb = nb + 4 <= pr.N ? nb : pr.N - 4;
-            const u16x4 zero = {0, 0, 0, 0};
-            biasv[ni] = pr.bias ? *reinterpret_cast<const u16x4*>(pr.bias + nb) : zero;
-        }
+    for (int ni = 0; ni < C::FB; ++ni) {
+        int nb = n0 + wn * C::TN + ni * 16 + 4 * fk0;
+        nb = nb + 4 <= pr.N ? nb : pr.N - 4;
+        const u16x4 zero = {0, 0, 0, 0};
+        biasv[ni] = pr.bias ? *reinterpret_cast<const u16x4*>(pr.bias + nb) : zero;
     }
+}
 
-    // ---- prologue: fill the ring
-    Stager<C> sg;
-    sg.init(pr, smem, m0, n0, w, lane);
-#pragma unroll
-    for (int s = 0; s < C::NS; ++s)
-        if (s < nkt) sg.issue(s);
-    if (nkt >= C::NS) wait_vm<(C::NS - 1) * C::PPW>();
-    else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-
-    // ---- main loop: per k-tile
-    //   MFMA(f0) || read f1 || 2nd half of the pending refill  |  f1 ready, tile kt+1 landed, barrier  |
-    //   MFMA(f1) || read next f0 || 1st half of the refill of the slot just freed
-    Frags<C> f0, f1;
-    read_frags<C>(f0, smem, wm, wn, 0, lane);
-    // pieces issued inside the first cluster after the barrier; a two-slot ring needs the whole refill there (the tile is
-    // waited for at the very next barrier), a deeper ring spreads it over both clusters
-    constexpr int PH = C::NS == 2 ? C::PPW : C::PPW / 2;
-    int slot = 0, pslot = 0;
-    bool pending = false;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const char* st = smem + slot * C::STAGE;
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): f0 (its reads ended half a cluster ago)
-        __builtin_amdgcn_sched_barrier(0);
-        mma<C, PH, C::PPW>(acc, f0, f1, st, 1, wm, wn, lane, sg, pslot, pending);
-        if (pending) sg.advance();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                // f1 arrived: this wave is done with `slot`
-        pending = false;
-        const bool more = kt + 1 < nkt;
-        const int nslot = slot + 1 == C::NS ? 0 : slot + 1;
-        if (more) {
-            if (kt + C::NS <= nkt) wait_vm<(C::NS - 2) * C::PPW>();         // tiles kt+2 .. kt+NS-1 may still be in flight
-            else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();                                  // tile kt+1 landed for everybody; `slot` is free
-            pending = kt + C::NS < nkt;
-            pslot = slot;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // (after the last k-tile this still reads a ring slot -- stale bytes, inside the ring, never used)
-        mma<C, 0, PH>(acc, f1, f0, smem + nslot * C::STAGE, 0, wm, wn, lane, sg, pslot, pending);
-        slot = nslot;
-    }
-    __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring becomes the epilogue tile
-
-    // ---- epilogue: acc -> (bias) -> bf16 tile in LDS -> whole row segments -> (+C | * gelu'(H)) -> global
+// ---- epilogue: acc * mul -> (bias) -> bf16 tile in LDS -> whole row segments -> (+C | * gelu'(H)) -> global
+template <class C, int EPI>
+__device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&acc)[C::FA][C::FB], const u16x4 (&biasv)[C::FB],
+                                         int tid, int lane, int wm, int wn, int m0, int n0, int tm, float mul) {
     // A thread owns ONE 16-byte column chunk of the tile and NIT rows (r = rr + it * RPP).  Whatever the row segments need from
     // memory (the old C of an accumulate, the pre-activation H) is requested for all NIT rows up front, before the transposition
     // through LDS: one round trip instead of NIT dependent ones.
@@ -397,7 +355,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
 #pragma unroll
         for (int mi = 0; mi < C::FA; ++mi) {
             const int ml = wm * C::TM + mi * 16 + frow;
-            const f32x4 v = acc[mi][ni] + bv;
+            const f32x4 v = acc[mi][ni] * mul + bv;
             const u16x4 o = {f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
             *reinterpret_cast<u16x4*>(smem + ml * C::CLD + nl * 2) = o;
         }
@@ -461,6 +419,199 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
             pr.part[(size_t)tm * pr.N + n0 + tid] = t;
         }
     }
+}
+
+template <class C, int EPI>
+__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w / C::WN, wn = w % C::WN;
+    const TileId ti = locate_tile<C>(P);
+    const Problem& pr = P.p[ti.pi];
+    const int m0 = ti.m0, n0 = ti.n0;
+    const int nkt = pr.K / BK;
+
+    f32x4 acc[C::FA][C::FB];
+#pragma unroll
+    for (int mi = 0; mi < C::FA; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::FB; ++ni) acc[mi][ni] = 0.f;
+    u16x4 biasv[C::FB];
+    load_bias<C>(pr, n0, wn, lane, biasv);
+
+    // ---- prologue: fill the ring
+    Stager<C> sg;
+    sg.init(pr, smem, m0, n0, w, lane);
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+        if (s < nkt) sg.issue(s);
+    if (nkt >= C::NS) wait_vm<(C::NS - 1) * C::PPW>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // ---- main loop: per k-tile
+    //   MFMA(f0) || read f1 || 2nd half of the pending refill  |  f1 ready, tile kt+1 landed, barrier  |
+    //   MFMA(f1) || read next f0 || 1st half of the refill of the slot just freed
+    Frags<C> f0, f1;
+    read_frags<C>(f0, smem, wm, wn, 0, lane);
+    // pieces issued inside the first cluster after the barrier; a two-slot ring needs the whole refill there (the tile is
+    // waited for at the very next barrier), a deeper ring spreads it over both clusters
+    constexpr int PH = C::NS == 2 ? C::PPW : C::PPW / 2;
+    int slot = 0, pslot = 0;
+    bool pending = false;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* st = smem + slot * C::STAGE;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): f0 (its reads ended half a cluster ago)
+        __builtin_amdgcn_sched_barrier(0);
+        mma<C, PH, C::PPW>(acc, f0, f1, st, 1, wm, wn, lane, sg, pslot, pending);
+        if (pending) sg.advance();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                // f1 arrived: this wave is done with `slot`
+        pending = false;
+        const bool more = kt + 1 < nkt;
+        const int nslot = slot + 1 == C::NS ? 0 : slot + 1;
+        if (more) {
+            if (kt + C::NS <= nkt) wait_vm<(C::NS - 2) * C::PPW>();         // tiles kt+2 .. kt+NS-1 may still be in flight
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();                                  // tile kt+1 landed for everybody; `slot` is free
+            pending = kt + C::NS < nkt;
+            pslot = slot;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (after the last k-tile this still reads a ring slot -- stale bytes, inside the ring, never used)
+        mma<C, 0, PH>(acc, f1, f0, smem + nslot * C::STAGE, 0, wm, wn, lane, sg, pslot, pending);
+        slot = nslot;
+    }
+    __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring becomes the epilogue tile
+
+    epilogue<C, EPI>(pr, smem, acc, biasv, tid, lane, wm, wn, m0, n0, ti.tm, 1.0f);
+}
+
+// ---- fp8 (OCP e4m3) operands, NT layout: forward projections of BASELINE.json configs[4] --------------------------------------
+//   C[M,N] (bf16) = (A8[M,K] . B8[N,K]^T) / (sA * sB) + bias,   A8 = sat(x * sA), B8 = sat(W * sB)  (per-tensor scales, on device)
+// Same ring, same LDS images and the same two conflict-free ds_read_b128 per fragment as the bf16 kernel -- a 128-byte LDS row
+// now holds 128 contraction elements -- but ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) per k-tile
+// and fragment pair: 2x the contraction per staged byte and 2x the bf16 matrix rate.  Which k a byte of the 32-byte operand
+// belongs to does not matter as long as A and B agree (both are read the same way): the instruction sums over all 128.
+// One MFMA cluster per k-tile; the next tile's fragments are read into a second register set inside it.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <class C>
+struct Frags8 {
+    bf16x8 a[2][C::FA];
+    bf16x8 b[2][C::FB];
+};
+
+template <class C>
+__device__ __forceinline__ i32x8 join(bf16x8 lo, bf16x8 hi) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 l = __builtin_bit_cast(i32x4, lo), h = __builtin_bit_cast(i32x4, hi);
+    const i32x8 v = {l.x, l.y, l.z, l.w, h.x, h.y, h.z, h.w};
+    return v;
+}
+
+template <class C>
+__device__ __forceinline__ void cluster8(f32x4 (&acc)[C::FA][C::FB], const Frags8<C>& f, Frags8<C>& fn, const char* nstage,
+                                         int wm, int wn, int lane, Stager<C>& sg, int slot, bool pending) {
+    constexpr int NM = C::FA * C::FB, NP = C::PPW, NSUB = NP + 1, NF = 2 * (C::FA + C::FB), RSUB = NSUB - 1;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb) {
+        const int m0 = sb * NM / NSUB, m1 = (sb + 1) * NM / NSUB;
+        const int t0 = sb < RSUB ? sb * NF / RSUB : NF, t1 = sb < RSUB ? (sb + 1) * NF / RSUB : NF;
+#pragma unroll
+        for (int t = t0; t < t1; ++t) {                                   // the next k-tile's fragments: a (both halves), then b
+            const int ks = t & 1, fi = t >> 1;
+            if (fi < C::FA) fn.a[ks][fi] = read_frag<true>(nstage, wm * C::TM + fi * 16, ks, lane);
+            else fn.b[ks][fi - C::FA] = read_frag<true>(nstage + C::A_BYTES, wn * C::TN + (fi - C::FA) * 16, ks, lane);
+        }
+#pragma unroll
+        for (int i = m0; i < m1; ++i) {
+            const int mi = i / C::FB, ni = i % C::FB;
+            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(join<C>(f.b[0][ni], f.b[1][ni]), join<C>(f.a[0][mi], f.a[1][mi]),
+                                                                            acc[mi][ni], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+#pragma unroll
+        for (int i = m0; i < m1; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i - m0 < t1 - t0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (sb + 1 < NSUB) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (pending) sg.template piece_rt<0, C::PPW>(sb, slot);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_f8_kernel(Params P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w / C::WN, wn = w % C::WN;
+    const TileId ti = locate_tile<C>(P);
+    const Problem& pr = P.p[ti.pi];
+    const int m0 = ti.m0, n0 = ti.n0;
+    const int nkt = pr.K / BK;                 // K counted in bf16-sized units (= 2 fp8 elements): 64 units = 128 bytes per row
+
+    f32x4 acc[C::FA][C::FB];
+#pragma unroll
+    for (int mi = 0; mi < C::FA; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::FB; ++ni) acc[mi][ni] = 0.f;
+    u16x4 biasv[C::FB];
+    load_bias<C>(pr, n0, wn, lane, biasv);
+    const float mul = 1.0f / (pr.scaleA[0] * pr.scaleB[0]);
+
+    Stager<C> sg;
+    sg.init(pr, smem, m0, n0, w, lane);
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+        if (s < nkt) sg.issue(s);
+    if (nkt >= C::NS) wait_vm<(C::NS - 1) * C::PPW>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+
+    Frags8<C> f0, f1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mi = 0; mi < C::FA; ++mi) f0.a[ks][mi] = read_frag<true>(smem, wm * C::TM + mi * 16, ks, lane);
+#pragma unroll
+        for (int ni = 0; ni < C::FB; ++ni) f0.b[ks][ni] = read_frag<true>(smem + C::A_BYTES, wn * C::TN + ni * 16, ks, lane);
+    }
+    int slot = 0;
+    // per k-tile: [this tile's fragments landed; tile kt+1 landed for everybody; slot kt free] -> one cluster: MFMAs of tile kt ||
+    // fragment reads of tile kt+1 || the DMA refill of slot kt.  Two named fragment sets: the loop body is written out twice.
+    for (int kt = 0; kt < nkt; kt += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (kt + half < nkt) {
+                const int k = kt + half;
+                __builtin_amdgcn_s_waitcnt(0xC07F);                            // lgkmcnt(0): the fragments of tile k
+                bool pending = false;
+                const int nslot = slot + 1 == C::NS ? 0 : slot + 1;
+                if (k + 1 < nkt) {
+                    if (k + C::NS <= nkt) wait_vm<(C::NS - 2) * C::PPW>();
+                    else wait_vm<0>();
+                    __builtin_amdgcn_s_barrier();
+                    pending = k + C::NS < nkt;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (half == 0) cluster8<C>(acc, f0, f1, smem + nslot * C::STAGE, wm, wn, lane, sg, slot, pending);
+                else cluster8<C>(acc, f1, f0, smem + nslot * C::STAGE, wm, wn, lane, sg, slot, pending);
+                if (pending) sg.advance();
+                __builtin_amdgcn_sched_barrier(0);
+                slot = nslot;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    epilogue<C, EPI_NONE>(pr, smem, acc, biasv, tid, lane, wm, wn, m0, n0, ti.tm, mul);
 }
 
 // ---- tile configurations ---------------------------------------------------------------------------------------------
@@ -535,7 +686,7 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
         d.band = d.tiles_n >= 8 ? 2 : 1;
         if (getenv("KVQ_GEMM_BAND")) d.band = atoi(getenv("KVQ_GEMM_BAND")) > 0 ? atoi(getenv("KVQ_GEMM_BAND")) : d.band;
         if (d.band > d.tiles_m) d.band = d.tiles_m;
-        d.C2 = nullptr; d.H = nullptr; d.part = nullptr;
+        d.C2 = nullptr; d.H = nullptr; d.part = nullptr; d.scaleA = nullptr; d.scaleB = nullptr;
         t0 += d.tiles_m * d.tiles_n;
     }
     for (int i = nprob; i < g2::MAX_PROBLEMS; ++i) P.p[i] = P.p[0];
@@ -576,6 +727,26 @@ int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hou
     hipStream_t st = (hipStream_t)stream;
     if (tile == KVQ_GEMM_TILE_256x192) return g2::launch_cfg<g2::Cfg256x192<true, true>, g2::EPI_GELU>(P, st);
     return g2::launch_cfg<g2::Cfg128x256<true, true>, g2::EPI_GELU>(P, st);
+}
+
+int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const float* scale_b, const void* bias, void* C, int M, int N,
+                    int K, int lda, int ldb, int ldc, void* stream) {
+    KVQ_REQUIRE(scale_a && scale_b, "kvq_gemm_fp8_nt: null scale pointer");
+    KVQ_REQUIRE(K > 0 && K % 128 == 0 && lda % 16 == 0 && ldb % 16 == 0, "kvq_gemm_fp8_nt: K %% 128 == 0 and lda, ldb %% 16 == 0 (fp8 elements)");
+    kvq_gemm_problem q;                         // the ring moves bytes: an fp8 row of K elements is a bf16 row of K / 2
+    q.A = A8; q.B = B8; q.C = C; q.bias = bias; q.M = M; q.N = N; q.K = K / 2; q.lda = lda / 2; q.ldb = ldb / 2; q.ldc = ldc; q.accumulate = 0;
+    g2::Params P;
+    if (int rc = build_params(&q, 1, KVQ_GEMM_NT, KVQ_GEMM_TILE_128x256, P, "kvq_gemm_fp8_nt")) return rc;
+    for (int i = 0; i < g2::MAX_PROBLEMS; ++i) { P.p[i].scaleA = scale_a; P.p[i].scaleB = scale_b; }
+    typedef g2::Cfg128x256<true, true> Cf;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g2::gemm2_f8_kernel<Cf>), hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+        if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm2_f8): %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((g2::gemm2_f8_kernel<Cf>), dim3((unsigned)P.ntiles), dim3(Cf::THREADS), Cf::LDS, (hipStream_t)stream, P);
+    return check_launch("gemm2_f8_kernel");
 }
 
 int64_t kvq_gemm_dgelu_partial_rows(int64_t M, int tile) {

@@ -80,6 +80,12 @@ SIGNATURES = {
                             C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
     "kvq_gemm_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_grouped_bf16": (_int, [C.POINTER(GemmProblem), _int, _int, _int, _vp]),
+    "kvq_fp8_quantize": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp, _vp]),
+    "kvq_fp8_state_floats": (_int, []),
+    "kvq_fp8_quantize_delayed": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp]),
+    "kvq_fp8_update_scales": (_int, [_vp, _int, _f32, _vp]),
+    "kvq_fp8_quantize_segments": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp]),
+    "kvq_gemm_fp8_nt": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_bf16_gelu": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_dgelu_partial_rows": (_i64, [_i64, _int]),
     "kvq_gemm_bf16_dgelu": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _int, _int, _int, _int, _int, _int, _int, _vp]),

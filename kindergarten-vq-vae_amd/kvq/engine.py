@@ -98,8 +98,8 @@ class FlatParams:
         for name, p, padded in entries:
             self.seg[name] = (off, p.numel(), p.shape)
             self.trainable[name] = p.requires_grad
-            off += _round_up(padded, 8)
-        self.n = _round_up(off, 8)
+            off += _round_up(padded, 16)       # 16 elements: an fp8 mirror of a segment stays 16-byte aligned
+        self.n = _round_up(off, 16)
         self.master = torch.zeros(self.n, dtype=torch.float32, device=device)
         for name, p, _ in entries:
             o, n, shape = self.seg[name]
@@ -119,7 +119,7 @@ class FlatParams:
             if not p.requires_grad:
                 continue
             o = self.seg[name][0]
-            e = o + _round_up(padded, 8)
+            e = o + _round_up(padded, 16)
             if self.ranges and self.ranges[-1][1] == o:
                 self.ranges[-1] = (self.ranges[-1][0], e)
             else:
@@ -226,7 +226,7 @@ class _StepGraphs:
 class TrainEngine:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False,
                  milestones=None, gamma=0.1, loss_recon_scale=1.0, loss_vq_scale=1.0, seed=1234,
-                 bucket_mib=64, process_group=None):
+                 bucket_mib=64, process_group=None, fp8_forward=None):
         self.model = model
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -381,6 +381,12 @@ class TrainEngine:
             if gq.n_embed > 1024:
                 raise KvqError("TrainEngine: the Gumbel row kernel holds at most 1024 codes")
             self.g_pw, self.g_pb, self.g_emb = add_aux(gq.proj.weight), add_aux(gq.proj.bias), add_aux(gq.embed.weight)
+        # extension (BASELINE.json configs[4], default off): forward GEMMs on the fp8 matrix cores, per-tensor just-in-time scales
+        self.fp8 = (os.environ.get("KVQ_FP8", "0") == "1") if fp8_forward is None else bool(fp8_forward)
+        if self.fp8:
+            if self.dtype != torch.bfloat16:
+                raise KvqError("TrainEngine: fp8 forward GEMMs need the bf16 compute dtype")
+            self._fp8_setup()
         _ENGINES[model] = self
         self._param_versions = self._versions()
         # gradient all-reduce chunks (tail first)
@@ -432,12 +438,81 @@ class TrainEngine:
     _OWN_DGELU = {}                                                             # (gy . W) * gelu'(h) + bias-gradient partials
     _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "256x192"}      # gW = gy^T . x          ("tn"), own launch
 
-    def _linear(self, x, wname, bname, fused=None, Wb=None):
+    # ---- fp8 forward GEMMs -------------------------------------------------------------------------------------------------
+    def _fp8_setup(self):
+        """One fp8 mirror of the flat bf16 shadow buffer; one quantisation segment (= one scale) per forward GEMM weight: the
+        fused q|k|v block, the all-layer cross-attention k|v block, every other [out, in] matrix, the padded LM-head table."""
+        fl = self.flat
+        segs = {}
+
+        def seg(key, names, rows=None):
+            o0 = fl.seg[names[0]][0]
+            n = sum(fl.seg[nm][1] for nm in names) if rows is None else rows * fl.seg[names[0]][2][1]
+            segs[key] = (o0, n)
+        for i in range(self.n_enc_layers):
+            pre = f"enc.{i}."
+            seg(pre + "sa.q.w", [pre + "sa.q.w", pre + "sa.k.w", pre + "sa.v.w"])
+            for nm in ("sa.o.w", "f1.w", "f2.w"):
+                seg(pre + nm, [pre + nm])
+        for i in range(self.n_dec_layers):
+            pre = f"dec.{i}."
+            seg(pre + "sa.q.w", [pre + "sa.q.w", pre + "sa.k.w", pre + "sa.v.w"])
+            for nm in ("sa.o.w", "ca.q.w", "ca.o.w", "f1.w", "f2.w"):
+                seg(pre + nm, [pre + nm])
+            if not self._cakv_batched:
+                seg(pre + "ca.k.w", [pre + "ca.k.w", pre + "ca.v.w"])
+        if self._cakv_batched:
+            seg(self._cakv_w[0], self._cakv_w)
+        seg("head.t.w", ["head.t.w"])
+        seg("dec.emb.word", ["dec.emb.word"], rows=self.Vp)
+        keys = list(segs)
+        self._w8_index = {k: i for i, k in enumerate(keys)}
+        offs = [segs[k][0] for k in keys]
+        ns = [segs[k][1] for k in keys]
+        assert all(o % 16 == 0 and n % 16 == 0 for o, n in zip(offs, ns))
+        self._w8 = torch.zeros(fl.n, dtype=torch.uint8, device=self.dev)
+        self._w8_off = torch.tensor(offs, dtype=torch.int64, device=self.dev)
+        self._w8_n = torch.tensor(ns, dtype=torch.int64, device=self.dev)
+        self._w8_max = max(ns)
+        self._w8_amax = torch.zeros(len(keys), dtype=torch.float32, device=self.dev)
+        self._w8_scale = torch.ones(len(keys), dtype=torch.float32, device=self.dev)
+        self._fp8_quantize_weights()
+        # activations: one {scale, amax} pair per GEMM input of the step, in call order (delayed scaling: include/kvq.h)
+        self._a8_sites = 8 * (self.n_enc_layers + self.n_dec_layers) + 8
+        st = torch.zeros((self._a8_sites, lib().kvq_fp8_state_floats()), dtype=torch.float32, device=self.dev)
+        st[:, 0] = 1.0
+        self._a8_state = st
+        self._a8_site = 0
+
+    def _fp8_quantize_weights(self):
+        """After every weight update: the GEMM weights of the whole model to fp8 in two launches."""
+        check(lib().kvq_fp8_quantize_segments(self.flat.shadow.data_ptr(), self._w8_off.data_ptr(), self._w8_n.data_ptr(), len(self._w8_index),
+                                              self._w8_max, self._w8.data_ptr(), self._w8_amax.data_ptr(), self._w8_scale.data_ptr(),
+                                              stream_ptr()), "kvq_fp8_quantize_segments")
+
+    def _linear_fp8(self, x, W, b, key):
+        si = self._w8_index[key]
+        o = self.flat.seg[key][0]
+        W8 = self._w8[o:o + W.numel()].view(W.shape)
+        site = self._a8_site
+        self._a8_site += 1
+        if site >= self._a8_sites:
+            raise KvqError("TrainEngine: more fp8 GEMM inputs in a step than scale slots")
+        st = self._a8_state[site]
+        x8 = torch.empty(x.shape, dtype=torch.uint8, device=self.dev)
+        check(lib().kvq_fp8_quantize_delayed(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), x8.data_ptr(), st.data_ptr(), stream_ptr()),
+              "kvq_fp8_quantize_delayed")
+        return nnops.gemm_fp8_nt(x8, W8, st[0:], self._w8_scale[si:], bias=b)
+
+    def _linear(self, x, wname, bname, fused=None, Wb=None, key=None):
         if Wb is not None:
             W, b = Wb
         else:
             W = self.flat.fused(fused[0], self.flat.shadow) if fused else self.flat.w(wname)
             b = self.flat.fused(fused[1], self.flat.shadow) if fused else self.flat.w(bname)
+            key = fused[0][0] if fused else wname
+        if self.fp8 and key in self._w8_index and x.shape[0] >= 256 and W.shape[1] % 128 == 0 and x.stride(1) == 1:
+            return self._linear_fp8(x, W, b, key)
         if self._own_fwd and self.dtype == torch.bfloat16 and x.shape[0] >= 2048 and x.stride(1) == 1:
             tile = self._OWN_FWD.get(tuple(W.shape))
             if tile is not None:
@@ -831,7 +906,12 @@ class TrainEngine:
         try:
             self._q_training = training if quantizer_training is None else bool(quantizer_training)
             with torch.no_grad():            # the schedule IS the backward pass: no autograd graph over the few torch ops in it
-                return self._forward_backward(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits)
+                if self.fp8:
+                    self._a8_site = 0
+                out = self._forward_backward(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits)
+                if self.fp8:                 # next call's activation scales from this call's amax (4x headroom)
+                    check(lib().kvq_fp8_update_scales(self._a8_state.data_ptr(), self._a8_sites, 4.0, stream_ptr()), "kvq_fp8_update_scales")
+                return out
         finally:
             nnops.set_seed_offset(None)
 
@@ -887,7 +967,8 @@ class TrainEngine:
         dec_saved = []
         kv_all = None
         if self._cakv_batched:             # keys | values of every decoder layer's cross-attention in one [N, L*2H] GEMM
-            kv_all = self._linear(enc_out, None, None, Wb=(fl.fused(self._cakv_w, fl.shadow), fl.fused(self._cakv_b, fl.shadow)))
+            kv_all = self._linear(enc_out, None, None, Wb=(fl.fused(self._cakv_w, fl.shadow), fl.fused(self._cakv_b, fl.shadow)),
+                                  key=self._cakv_w[0])
         for i in range(self.n_dec_layers):
             y, sa = self._attn_block_fwd(f"dec.{i}.sa.", y, None, d_mask, True, dcfg, training, B, Sd, Sd)
             y, ca = self._attn_block_fwd(f"dec.{i}.ca.", y, enc_out, None, False, dcfg, training, B, Sd, S,
@@ -898,7 +979,7 @@ class TrainEngine:
         hN, hpre, hmean, hrstd = nnops.ln_fwd(ta, None, fl.w32("head.ln.w"), fl.w32("head.ln.b"), dcfg.layer_norm_eps)
         Wv = fl.w("dec.emb.word", rows=self.Vp)                              # [Vp,H], rows >= V are zero
         bv = fl.shadow[fl.seg["head.bias"][0]: fl.seg["head.bias"][0] + self.Vp]
-        logits = self._linear(hN, None, None, Wb=(Wv, bv))                    # [N,Vp]
+        logits = self._linear(hN, None, None, Wb=(Wv, bv), key="dec.emb.word")  # [N,Vp]
         tgt = d_ids.reshape(-1)
         row_loss = torch.empty(Nd, dtype=torch.float32, device=self.dev)
         row_lse = torch.empty(Nd, dtype=torch.float32, device=self.dev)
@@ -1141,6 +1222,8 @@ class TrainEngine:
                                     b1, b2, self.eps, self.wd, vmax=a["vmax"].view(-1) if a["vmax"] is not None else None)
         if self.vq_kind in ("VectorQuantizer", "MultiVectorQuantizer") and self.E.requires_grad:
             self._repack_codebook()
+        if self.fp8:
+            self._fp8_quantize_weights()
 
 
     def _versions(self):
@@ -1152,12 +1235,16 @@ class TrainEngine:
         v = self._versions()
         if v != self._param_versions:
             self.flat.refresh_shadow()
+            if self.fp8:
+                self._fp8_quantize_weights()
             self._param_versions = v
 
     def sync_from_model(self):
         """Call after the model's parameters were written from outside (load_state_dict, manual init): refreshes the bf16
         shadow weights the GEMMs read.  (The f32 master buffer IS the parameters' storage, nothing to copy there.)"""
         self.flat.refresh_shadow()
+        if self.fp8:
+            self._fp8_quantize_weights()
 
     @staticmethod
     def supports(model, seq_len: int) -> bool:

@@ -303,3 +303,27 @@ def gemm_dgelu(gy, w, h, tile="256x192"):
     check(l.kvq_gemm_bf16_dgelu(gy.data_ptr(), w.data_ptr(), h.data_ptr(), out.data_ptr(), part.data_ptr(), part.numel() * 4, M, N, K,
                                 gy.stride(0), w.stride(0), out.stride(0), t, stream_ptr()), "kvq_gemm_bf16_dgelu")
     return out, part
+
+
+# ---- fp8 forward GEMMs (csrc/kvq_fp8.hip, kvq_gemm_fp8_nt) -----------------------------------------------------------------------
+def fp8_quantize(x, out=None):
+    """bf16 [rows, cols] (unit column stride) -> (fp8 bytes [rows, cols] as uint8, scale [1] f32 on the device)."""
+    require_gpu(x)
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    st = torch.empty(2, dtype=torch.float32, device=x.device)             # [amax, scale]
+    check(lib().kvq_fp8_quantize(x.data_ptr(), rows, cols, x.stride(0), out.data_ptr(), st[0:].data_ptr(), st[1:].data_ptr(), stream_ptr()),
+          "kvq_fp8_quantize")
+    return out, st[1:]
+
+
+def gemm_fp8_nt(a8, b8, scale_a, scale_b, bias=None, out=None):
+    """out[M,N] bf16 = (a8[M,K] @ b8[N,K].T) / (scale_a * scale_b) + bias on the fp8 matrix cores."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a8.device)
+    check(lib().kvq_gemm_fp8_nt(a8.data_ptr(), b8.data_ptr(), scale_a.data_ptr(), scale_b.data_ptr(), _p(bias), out.data_ptr(), M, N, K,
+                                a8.stride(0), b8.stride(0), out.stride(0), stream_ptr()), "kvq_gemm_fp8_nt")
+    return out

@@ -1,0 +1,98 @@
+"""fp8 (OCP e4m3fn) forward GEMMs -- the extension named by BASELINE.json configs[4] (the reference is f32 throughout):
+quantisation kernels against torch's float8_e4m3fn conversion, the fp8 MFMA GEMM against an f32 matmul of the dequantised
+operands, and the TrainEngine with fp8 forward GEMMs against the bf16 engine (loss parity; backward stays bf16)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_quant(x):
+    amax = x.float().abs().max()
+    scale = 448.0 / amax
+    q = (x.float() * scale).clamp(-448, 448).cpu().to(torch.float8_e4m3fn)
+    return q, scale.item()
+
+
+def test_quantize_matches_torch_float8_conversion():
+    from kvq import nnops
+    torch.manual_seed(0)
+    big = (torch.randn(300, 520, device="cuda") * 3).to(torch.bfloat16)
+    x = big[:, 8:8 + 504]                                   # row stride 520, 16-byte aligned start
+    q, scale = nnops.fp8_quantize(x)
+    want, s = _ref_quant(x)
+    np.testing.assert_allclose(scale.item(), s, rtol=1e-6)
+    got = q.cpu().view(torch.float8_e4m3fn).float()
+    assert torch.equal(got, want.float())
+    assert got.abs().max().item() == 448.0                  # the largest element lands exactly on the largest e4m3 value
+
+
+@pytest.mark.parametrize("shape", [(512, 768, 256), (1000, 776, 384), (8192, 768, 768), (2048, 3072, 768), (40, 24, 128)])
+def test_fp8_gemm_equals_f32_matmul_of_the_dequantised_operands(shape):
+    from kvq import nnops
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device="cuda").to(torch.bfloat16)
+    x8, sx = nnops.fp8_quantize(x)
+    w8, sw = nnops.fp8_quantize(w)
+    out = nnops.gemm_fp8_nt(x8, w8, sx, sw, bias=bias)
+    xf = x8.cpu().view(torch.float8_e4m3fn).float().cuda()
+    wf = w8.cpu().view(torch.float8_e4m3fn).float().cuda()
+    ref = (xf @ wf.t()) / (sx * sw) + bias.float()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2.0 ** -8 * ref.abs().max().item() + 1e-3, err        # only the bf16 rounding of the result
+    # and the quantisation itself stays within e4m3's resolution of the bf16 product
+    true = x.float() @ w.float().t() + bias.float()
+    rel = (out.float() - true).norm().item() / true.norm().item()
+    assert rel < 5e-2, rel
+
+
+def _build(seed=0):
+    from models.shelgon3.Shelgon import Shelgon
+    from models.shelgon3.VectorQuantizer import VectorQuantizer
+    torch.manual_seed(seed)
+    vq = VectorQuantizer(512, 768, 0.25, vq_codebook_init_values=torch.randn(512, 768))
+    vq.materialize_min_encodings = False
+    return Shelgon("kvq-bert-base-2l", vq, "kvq-bert-base-2l", None, compute_dtype=torch.bfloat16).cuda().eval()
+
+
+def test_engine_fp8_forward_against_the_bf16_engine():
+    """bert-base widths, 2 layers, 2048 tokens: every forward GEMM on the fp8 matrix cores, backward in bf16.
+    Stated tolerance: reconstruction loss within 2e-2 relative of the bf16 engine, VQ loss within 5e-2; gradients point the
+    same way (cosine > 0.9 per tensor, > 0.98 on average)."""
+    from dsentences.synthetic import random_token_batch
+    from kvq.engine import TrainEngine
+    ids, mask = (t.cuda() for t in random_token_batch(64, 32, torch.Generator().manual_seed(4)))
+    runs = {}
+    for fp8 in (False, True):
+        model = _build()
+        eng = TrainEngine(model, lr=1e-4, fp8_forward=fp8)
+        out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+        grads = {n: eng.flat.g(n).float().clone() for n, p in eng.param_of.items() if p.requires_grad}
+        runs[fp8] = (out["loss_recon"].item(), out["loss_vq"].item(), out["indices"].clone(), grads, eng)
+    (l0, v0, i0, g0, _), (l1, v1, i1, g1, e8) = runs[False], runs[True]
+    np.testing.assert_allclose(l1, l0, rtol=2e-2)
+    np.testing.assert_allclose(v1, v0, rtol=5e-2)
+    assert (i0 == i1).float().mean().item() > 0.9
+    cos = [F.cosine_similarity(g1[n].reshape(-1), g0[n].reshape(-1), dim=0).item() for n in g0 if g0[n].norm() > 0 and not n.endswith("k.b")]
+    assert min(cos) > 0.9 and np.mean(cos) > 0.98, (min(cos), np.mean(cos))
+    # the weight mirror: every segment is the torch conversion of the bf16 shadow at that segment's own scale
+    key = "enc.0.f1.w"
+    si, (o, n, shape) = e8._w8_index[key], e8.flat.seg[key]
+    want, s = _ref_quant(e8.flat.shadow[o:o + n])
+    np.testing.assert_allclose(e8._w8_scale[si].item(), s, rtol=1e-6)
+    assert torch.equal(e8._w8[o:o + n].cpu().view(torch.float8_e4m3fn).float(), want.float())
+
+
+def test_engine_fp8_trains_through_graph_replay():
+    from dsentences.synthetic import random_token_batch
+    from kvq.engine import TrainEngine
+    model = _build(1).train()
+    eng = TrainEngine(model, lr=2e-4, fp8_forward=True)
+    ids, mask = (t.cuda() for t in random_token_batch(64, 32, torch.Generator().manual_seed(5)))
+    losses = [float(eng.train_step(ids, mask)["loss_recon"]) for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] and eng._graphs, losses
