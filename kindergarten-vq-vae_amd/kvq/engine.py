@@ -364,7 +364,7 @@ class TrainEngine:
         if self.vq_kind in ("VectorQuantizer", "MultiVectorQuantizer"):
             vq = model.vector_quantizer
             self.G = int(getattr(vq, "n_factors", 1))         # codebooks = slices of the encoder output, one grouped launch
-            self.K, self.Dg = int(vq.n_e), self.H // self.G
+            self.K, self.Dg = int(vq.n_e), int(getattr(vq, "d_factor", self.H))       # (padded) slice width
             self.E = vq.embedding.weight                      # f32 [G*K, H/G]
             if self.E.shape != (self.G * self.K, self.Dg):
                 raise KvqError(f"TrainEngine: codebook {tuple(self.E.shape)} does not match {self.G} x {self.K} x {self.Dg}")
@@ -1110,13 +1110,15 @@ class TrainEngine:
             self._vq_fwd_call(z, N, H, 1, z_q, idx, vq_out[0:], vq_out[1:], ws)
             zsrc = z
         else:
+            vq = self.model.vector_quantizer
             zg = self._buf("zg", (G, N, Dg), z.dtype)
-            zg.copy_(z.view(N, G, Dg).permute(1, 0, 2))
+            zg.copy_(vq.split(z))
             zqg = self._buf("zqg", (G, N, Dg), z.dtype)
             lp = self._buf("lp", (2, G), torch.float32)
             self._vq_fwd_call(zg, N, Dg, G, zqg, idx, lp[0], lp[1], ws)
-            z_q.view(N, G, Dg).copy_(zqg.permute(1, 0, 2))
-            vq_out.copy_(lp.mean(1))
+            z_q.copy_(vq.merge(zqg))
+            vq_out[0:1].copy_(lp[0].sum(0, keepdim=True) * vq.loss_weight)          # (1 + beta) * MSE over all N * e_dim elements
+            vq_out[1:2].copy_(lp[1].mean(0, keepdim=True))
             zsrc = zg
         if self.vq_ema:                      # the EMA step runs after backward: keep what it needs in storage of its own
             self._buf("ema_z", zsrc.shape, zsrc.dtype).copy_(zsrc)
@@ -1128,22 +1130,21 @@ class TrainEngine:
         G, K, Dg = self.G, self.K, self.Dg
         ws = _workspace(self.dev, lib().kvq_vq_workspace_bytes(N, K, Dg, G))
         gE = self.gE.data_ptr() if self.E.requires_grad else None
-        g_z = torch.empty_like(z)
         if G == 1:
+            g_z = torch.empty_like(z)
             gl = self._ones * self.w_vq
             check(lib().kvq_vq_backward(z.data_ptr(), self.E.data_ptr(), idx.data_ptr(), g_enc.data_ptr(), gl.data_ptr(), N, K, H, 1,
                                         self.io, self.beta_vq, g_z.data_ptr(), gE, ws.data_ptr(), ws.numel(), stream_ptr()),
                   "kvq_vq_backward")
             return g_z
-        zg = z.view(N, G, Dg).permute(1, 0, 2).contiguous()
-        gq = g_enc.view(N, G, Dg).permute(1, 0, 2).contiguous()
-        gl = torch.full((G,), self.w_vq / G, dtype=torch.float32, device=self.dev)       # loss = mean over the factors
+        vq = self.model.vector_quantizer
+        zg, gq = vq.split(z), vq.split(g_enc)
+        gl = torch.full((G,), self.w_vq * vq.loss_weight, dtype=torch.float32, device=self.dev)
         gzg = torch.empty_like(zg)
         check(lib().kvq_vq_backward(zg.data_ptr(), self.E.data_ptr(), idx.data_ptr(), gq.data_ptr(), gl.data_ptr(), N, K, Dg, G,
                                     self.io, self.beta_vq, gzg.data_ptr(), gE, ws.data_ptr(), ws.numel(), stream_ptr()),
               "kvq_vq_backward")
-        g_z.view(N, G, Dg).copy_(gzg.permute(1, 0, 2))
-        return g_z
+        return vq.merge(gzg)
 
     def _ema_step(self):
         zs, zdt, ishape = self._ema_shapes

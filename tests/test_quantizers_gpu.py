@@ -27,29 +27,42 @@ def _batch(B=6, S=12, seed=1, vocab=2000):
     return ids.cuda(), (ids != 0).long().cuda()
 
 
-def test_multi_vector_quantizer_equals_one_oracle_call_per_factor():
+@pytest.mark.parametrize("D", [576, 768])
+def test_multi_vector_quantizer_equals_one_oracle_call_per_factor(D):
+    """9 factors on 576 columns (9 x 64) and on bert-base's 768 (slices of 86 / 85 columns, zero-padded to 96 inside)."""
     from models.shelgon3.MultiVectorQuantizer import MultiVectorQuantizer
-    G, K, D, B, S = 9, 32, 576, 4, 7
+    G, K, B, S = 9, 32, 4, 7
     torch.manual_seed(0)
     mq = MultiVectorQuantizer(G, K, D, 0.25).cuda()
-    mq.embedding.weight.data.normal_()
+    W = mq.embedding.weight.data
+    W.copy_(torch.randn_like(W) * (W != 0 if mq.ragged else 1))          # pad columns of the codebooks stay zero
     z = torch.randn(B, S, D, device="cuda", requires_grad=True)
     loss, z_q, perp, enc, idx = mq(z, "cuda")
     assert enc is None and idx.shape == (B, S, G) and z_q.shape == z.shape
     (loss * 1.7 + (z_q * torch.arange(D, device="cuda").float()).sum()).backward()
-    E = mq.embedding.weight.detach().cpu().numpy().reshape(G, K, D // G)
-    zn = z.detach().cpu().numpy().reshape(B * S, G, D // G)
-    g_up = np.broadcast_to(np.arange(D, dtype=np.float32), (B * S, D)).reshape(B * S, G, D // G)
-    losses, perps = [], []
+    base, rem = divmod(D, G)
+    widths = [base + (g < rem) for g in range(G)]
+    offs = np.concatenate([[0], np.cumsum(widths)])
+    Ep = mq.embedding.weight.detach().cpu().numpy().reshape(G, K, mq.d_factor)
+    gEp = mq.embedding.weight.grad.cpu().numpy().reshape(G, K, mq.d_factor)
+    zn = z.detach().cpu().numpy().reshape(B * S, D)
+    g_up = np.broadcast_to(np.arange(D, dtype=np.float32), (B * S, D))
+    sse, perps = 0.0, []
     for g in range(G):
-        ora = O.vq_forward(np.ascontiguousarray(zn[:, g]), E[g], 0.25)
+        sl = slice(offs[g], offs[g + 1])
+        w = widths[g]
+        zs, Eg = np.ascontiguousarray(zn[:, sl]), np.ascontiguousarray(Ep[g][:, :w])
+        ora = O.vq_forward(zs, Eg, 0.25)
         assert np.array_equal(idx[..., g].reshape(-1).cpu().numpy(), ora["idx"]), f"factor {g}"
-        assert np.array_equal(z_q.detach().reshape(B * S, G, -1)[:, g].cpu().numpy(), ora["z_q"])
-        losses.append(ora["loss"]); perps.append(ora["perplexity"])
-        gz, gE = O.vq_backward(np.ascontiguousarray(zn[:, g]), E[g], ora["idx"], np.ascontiguousarray(g_up[:, g]), 1.7 / G, 0.25)
-        np.testing.assert_allclose(z.grad.reshape(B * S, G, -1)[:, g].cpu().numpy(), gz, rtol=1e-5, atol=1e-7)
-        np.testing.assert_allclose(mq.embedding.weight.grad.cpu().numpy().reshape(G, K, -1)[g], gE, rtol=2e-5, atol=1e-7)
-    np.testing.assert_allclose(loss.item(), np.mean(losses), rtol=1e-6)
+        assert np.array_equal(z_q.detach().reshape(B * S, D)[:, sl].cpu().numpy(), ora["z_q"])
+        sse += ora["loss"] * w
+        perps.append(ora["perplexity"])
+        # d total / d loss_g' = 1.7 * w / D for the oracle's per-slice mean
+        gz, gE = O.vq_backward(zs, Eg, ora["idx"], np.ascontiguousarray(g_up[:, sl]), 1.7 * w / D, 0.25)
+        np.testing.assert_allclose(z.grad.reshape(B * S, D)[:, sl].cpu().numpy(), gz, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(gEp[g][:, :w], gE, rtol=2e-5, atol=1e-7)
+        assert not gEp[g][:, w:].any() and not Ep[g][:, w:].any()         # pad columns: zero value, zero gradient
+    np.testing.assert_allclose(loss.item(), sse / D, rtol=2e-6)
     np.testing.assert_allclose(perp.item(), np.mean(perps), rtol=1e-5)
 
 
@@ -78,13 +91,16 @@ def _compare_engine_with_autograd(model, ids, mask, eng, skip=()):
     return ref, out
 
 
-def test_engine_runs_the_nine_factor_quantiser_as_one_grouped_launch():
-    """hidden 576 = 9 heads x 64: nine codebooks of 32 codes on nine 64-wide slices; engine == autograd through the module."""
+@pytest.mark.parametrize("name,D", [("kvq-bert-9x64", 576), ("kvq-bert-tiny-nodrop", 128)])
+def test_engine_runs_the_nine_factor_quantiser_as_one_grouped_launch(name, D):
+    """Nine codebooks of 32 codes: hidden 576 = nine 64-wide slices, and hidden 128 = ragged slices (15 / 14 columns, padded to 32);
+    engine == autograd through the module."""
     from kvq.engine import TrainEngine
     from models.shelgon3.MultiVectorQuantizer import MultiVectorQuantizer
-    mq = MultiVectorQuantizer(9, 32, 576, 0.25)
-    mq.embedding.weight.data.normal_()
-    model = _model(mq, "kvq-bert-9x64").train()
+    mq = MultiVectorQuantizer(9, 32, D, 0.25)
+    W = mq.embedding.weight.data
+    W.copy_(torch.randn_like(W) * (W != 0 if mq.ragged else 1))
+    model = _model(mq, name).train()
     ids, mask = _batch(B=5, S=12, seed=3)
     eng = TrainEngine(model, lr=1e-3)
     assert eng.G == 9 and TrainEngine.supports(model, 12)
