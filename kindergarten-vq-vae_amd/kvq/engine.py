@@ -272,6 +272,7 @@ class TrainEngine:
         # hipGraphs: 23.6 ms/step against 22.5 ms on one stream -- two concurrent hipBLASLt kernels share CUs and L2 badly
         self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get("KVQ_WG_STREAM", "0") == "1" else None
         self._wg_pending = False
+        self._wg_keep_step = []
         self.use_graph = os.environ.get("KVQ_GRAPH", "1") != "0"
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -545,16 +546,29 @@ class TrainEngine:
         """The weight gradients queued since the last flush (one layer's worth) as one grouped launch: ~250 tiles of 128 x 256,
         one per CU over the whole token contraction, written straight into the flat bf16 gradient buffer."""
         items = self._wg_items
-        for i in range(0, len(items), 8):
-            nnops.gemm_grouped(items[i:i + 8], "tn", "128x256")
+        if self.wg_stream is not None:
+            # KVQ_WG_STREAM=1: the layer's weight gradients run on a side stream while the main stream goes on with the next
+            # layer's backward chain (nothing there reads them); joined at the end of backward / before an all-reduce
+            self.wg_stream.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self.wg_stream):
+                for i in range(0, len(items), 8):
+                    nnops.gemm_grouped(items[i:i + 8], "tn", "128x256")
+            self._wg_pending = True
+            self._wg_keep_step += self._wg_keep            # operands stay alive until the join
+        else:
+            for i in range(0, len(items), 8):
+                nnops.gemm_grouped(items[i:i + 8], "tn", "128x256")
         self._wg_items, self._wg_keep = [], []
+
+    def _join_wgrads(self):
+        if self._wg_pending:
+            torch.cuda.current_stream(self.dev).wait_stream(self.wg_stream)
+            self._wg_pending = False
+        self._wg_keep_step = []
 
     def _flush_reductions(self):
         if self._wg_items:
             self._flush_wgrads()
-        if self._wg_pending:                     # weight-gradient GEMMs of this layer ran on the side stream: join it first
-            torch.cuda.current_stream(self.dev).wait_stream(self.wg_stream)
-            self._wg_pending = False
         if self._red_items:
             nnops.reduce_batch(self._red_items)
         self._red_items, self._red_keep = [], []
@@ -585,14 +599,7 @@ class TrainEngine:
         """gW = gy^T x.  Nothing on the way to the next layer's gradient needs it; with KVQ_WG_STREAM=1 it runs on a side stream
         next to the input-gradient GEMM (a fork / join inside the captured hipGraph, joined by the layer's batched reduction).
         Off by default: it measured 5 % slower than one stream."""
-        if self.wg_stream is None:
-            return self._wgrad_on_current_stream(gy, x, out)
-        main = torch.cuda.current_stream(self.dev)
-        self.wg_stream.wait_stream(main)                   # gy (and out's previous readers) are ordered before
-        with torch.cuda.stream(self.wg_stream):
-            self._wgrad_on_current_stream(gy, x, out)
-        self._wg_pending = True
-        self._red_keep += [gy, x]                          # alive (not handed back to the allocator) until the join
+        return self._wgrad_on_current_stream(gy, x, out)
 
     def _wgrad_on_current_stream(self, gy, x, out):
         Ntok, M = gy.shape
@@ -809,6 +816,7 @@ class TrainEngine:
         self._flush_reductions()
         if self.world == 1:
             return
+        self._join_wgrads()
         lo = self.flat.seg[name][0]
         while self._pending_hi - self.chunk >= lo:
             self._reduce(self._pending_hi - self.chunk, self._pending_hi)
@@ -1072,6 +1080,7 @@ class TrainEngine:
                 enc_saved[i] = None
             self._emb_bwd("enc.emb.", g_x, emb_saved)
         self._flush_reductions()
+        self._join_wgrads()
         return out
 
     def _buf(self, name, shape, dtype):
@@ -1299,7 +1308,7 @@ class TrainEngine:
                 self._works, self._works_late = [], []
             self._pending_hi = self.flat.n
         self._red_items, self._red_keep, self._wg_pending = [], [], False
-        self._wg_items, self._wg_keep = [], []
+        self._wg_items, self._wg_keep, self._wg_keep_step = [], [], []
 
     def eval_step(self, input_ids, attention_mask):
         return self.forward_backward(input_ids, attention_mask, training=False, compute_grads=False)
