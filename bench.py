@@ -181,13 +181,19 @@ def main():
         es = 2 if dtype == torch.bfloat16 else 4
         flops = 2.0 * N_tok * a.codes * D                                      # distance contraction
         alg_bytes = N_tok * (2 * D * es + 8) + a.codes * D * 4                  # read z, write z_q, write idx, codebook once
-        traffic = None
+        traffic = fwd_traffic = None
         tpath = os.path.join(ROOT, "profiles", "vq_fwd_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"N{N_tok}_K{a.codes}_D{D}_{a.dtype}")
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"N{N_tok}_K{a.codes}_D{D}_{a.dtype}")
+                fwd_traffic = tj.get(f"forward_kernels_N{N_tok}_K{a.codes}_D{D}_{a.dtype}")
             except Exception:
-                traffic = None
+                traffic = fwd_traffic = None
+        # the distance kernel's own algorithmic bytes: z once, the codebook once, one 8-byte key per token; at the L2 <-> fabric
+        # level (where FETCH_SIZE counts) each of the 8 XCD L2s needs its own copy of the codebook
+        dist_alg = N_tok * D * es + a.codes * D * 4 + N_tok * 8
+        dist_floor = N_tok * D * es + 8 * a.codes * D * 4 + N_tok * 8
         ach_tflops = flops / (vq_avg_ms * 1e-3) / 1e12 if vq_ms else None
         out = {
             "metric": "dSentences train sentences/sec",
@@ -209,7 +215,9 @@ def main():
                 "kernel": "vq_dist_packed_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": (ach_tflops / F32_MFMA_PEAK_TFLOPS) if ach_tflops else None,
                 "traffic": traffic, "avg_launch_us": vq_avg_ms * 1e3 if vq_ms else None, "launches": len(vq_ms),
-                "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                "flops_per_launch": flops, "algorithmic_bytes_per_launch": dist_alg, "fabric_floor_bytes_per_launch": dist_floor,
+                "forward": {"algorithmic_bytes": alg_bytes, "traffic": sum(fwd_traffic.values()) if fwd_traffic else None,
+                            "kernels": fwd_traffic},
                 "hbm": {"achieved": alg_bytes / (vq_avg_ms * 1e-3) / 1e9 if vq_ms else None, "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": alg_bytes / (vq_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if vq_ms else None},
             },

@@ -174,3 +174,21 @@ def test_bert_plan_equals_huggingface_forward():
     m(ids, mask, ids, mask).square().mean().backward()
     missing = [n for n, p in m.named_parameters() if p.grad is None and "pooler" not in n]
     assert not missing, missing
+
+
+def test_bench_refuses_to_report_a_number_for_a_job_size_it_did_not_run():
+    """`python bench.py --gpus 4` without a launcher must start 4 ranks itself or FAIL -- never print a 1-GPU line with rc 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KVQ_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 4:
+        assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and '"metric"' not in r.stdout
+    # launched by a launcher with a different world size: refuse as well
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and '"metric"' not in r.stdout

@@ -55,9 +55,11 @@ for k, c in agg.items():
 out += ["", "MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs). The distance kernel's busy count equals the theoretical "
             "2NKD / 64 FLOP-per-clock = 1.007e8 cycles: no redundant matrix work.", ""]
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(out))
-dk = [k for k in traffic if "dist_packed" in k or "dist_tile" in k]
+dk = [k for k in traffic if "dist_packed" in k]
 if dk:
-    json.dump({"N8192_K512_D768_bfloat16": traffic[dk[0]], "_kernel": dk[0],
-               "_source": f"profiles/{tag}_summary.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch"},
+    fwd = {k: traffic[k] for k in traffic if any(t in k for t in ("dist_packed", "vq_epilogue", "vq_finalize"))}
+    json.dump({"N8192_K512_D768_bfloat16": traffic[dk[0]], "_kernel": dk[0], "forward_kernels_N8192_K512_D768_bfloat16": fwd,
+               "_source": f"profiles/{tag}_summary.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                          f"launch; the factor 2 on FETCH_SIZE holds for 4-, 8- and 16-byte loads per lane alike (calibration in profiles/{tag}_gemm_pmc.md)"},
               open("profiles/vq_fwd_traffic.json", "w"), indent=1)
 print("\n".join(out[-14:]))
