@@ -280,9 +280,8 @@ struct TileId {
     int pi, tm, tn, m0, n0;
 };
 template <class C>
-__device__ __forceinline__ TileId locate_tile(const Params& P) {
+__device__ __forceinline__ TileId locate_tile(const Params& P, int id) {
     // XCD-aware numbering (bijective form), then problem lookup
-    int id = blockIdx.x;
     {
         const int nt = P.ntiles, q = nt >> 3, r = nt & 7, x = id & 7;
         id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
@@ -423,31 +422,10 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
     }
 }
 
-template <class C, int EPI>
-__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w / C::WN, wn = w % C::WN;
-    const TileId ti = locate_tile<C>(P);
-    const Problem& pr = P.p[ti.pi];
-    const int m0 = ti.m0, n0 = ti.n0;
-    const int nkt = pr.K / BK;
-
-    f32x4 acc[C::FA][C::FB];
-#pragma unroll
-    for (int mi = 0; mi < C::FA; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < C::FB; ++ni) acc[mi][ni] = 0.f;
-    u16x4 biasv[C::FB];
-    load_bias<C>(pr, n0, wn, lane, biasv);
-
-    // ---- prologue: fill the ring
-    Stager<C> sg;
-    sg.init(pr, smem, m0, n0, w, lane);
-#pragma unroll
-    for (int s = 0; s < C::NS; ++s)
-        if (s < nkt) sg.issue(s);
+// ---- the k loop of one tile.  On entry the ring holds k-tiles 0 .. min(NS, nkt) - 1 of the tile (issued, not yet waited for)
+//      and `sg` points at k-tile NS; on exit every wave has read its last fragments (the ring is free).
+template <class C>
+__device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& sg, char* smem, int nkt, int wm, int wn, int lane) {
     if (nkt >= C::NS) wait_vm<(C::NS - 1) * C::PPW>();
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
@@ -485,10 +463,43 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
         mma<C, 0, PH>(acc, f1, f0, smem + nslot * C::STAGE, 0, wm, wn, lane, sg, pslot, pending);
         slot = nslot;
     }
-    __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring becomes the epilogue tile
+    __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring is free (it becomes the epilogue tile)
+}
 
+template <class C, int EPI>
+__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w / C::WN, wn = w % C::WN;
+    const TileId ti = locate_tile<C>(P, blockIdx.x);
+    const Problem& pr = P.p[ti.pi];
+    const int m0 = ti.m0, n0 = ti.n0;
+    const int nkt = pr.K / BK;
+
+    f32x4 acc[C::FA][C::FB];
+#pragma unroll
+    for (int mi = 0; mi < C::FA; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::FB; ++ni) acc[mi][ni] = 0.f;
+    u16x4 biasv[C::FB];
+    load_bias<C>(pr, n0, wn, lane, biasv);
+
+    // ---- prologue: fill the ring
+    Stager<C> sg;
+    sg.init(pr, smem, m0, n0, w, lane);
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+        if (s < nkt) sg.issue(s);
+    mainloop<C>(acc, sg, smem, nkt, wm, wn, lane);
     epilogue<C, EPI>(pr, smem, acc, biasv, tid, lane, wm, wn, m0, n0, ti.tm, 1.0f);
 }
+
+// (A persistent form -- gridDim.x = CUs workgroups walking the tiles, the next tile's ring issued before this tile's epilogue, the
+//  epilogue transposed through two LDS pass regions behind the ring -- was built and measured in round 2 and removed again:
+//  256x192 tiles 41.7 vs 43.6 us on the FFN1 shape and 228 vs 236 us on the cross-K/V shape, but 394 vs 389 us on the LM head, and
+//  256x256 tiles (16-row passes, 16 barriers per tile) 442 vs 357 us.  vmcnt being one in-order queue for loads and stores, the next
+//  tile's first waits also wait for the previous tile's stores, which is most of what the overlap was meant to hide.)
 
 // ---- fp8 (OCP e4m3) operands, NT layout: forward projections of BASELINE.json configs[4] --------------------------------------
 //   C[M,N] (bf16) = (A8[M,K] . B8[N,K]^T) / (sA * sB) + bias,   A8 = sat(x * sA), B8 = sat(W * sB)  (per-tensor scales, on device)
@@ -554,7 +565,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_f8_kernel(Para
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / C::WN, wn = w % C::WN;
-    const TileId ti = locate_tile<C>(P);
+    const TileId ti = locate_tile<C>(P, blockIdx.x);
     const Problem& pr = P.p[ti.pi];
     const int m0 = ti.m0, n0 = ti.n0;
     const int nkt = pr.K / BK;                 // K counted in bf16-sized units (= 2 fp8 elements): 64 units = 128 bytes per row

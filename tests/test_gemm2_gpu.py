@@ -136,3 +136,21 @@ def test_gemm_dgelu_epilogue_and_bias_partials(tile):
     torch.testing.assert_close(part.sum(0), g_h.float().sum(0), rtol=1e-4, atol=1e-2)
     for t in range(part.shape[0]):                                # each partial row is exactly its row tile's column sum
         torch.testing.assert_close(part[t], g_h[t * bm:(t + 1) * bm].float().sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("tile", ["256x192", "256x256"])
+@pytest.mark.parametrize("shape", [(8192, 3072, 768), (8192, 2312, 256), (4104, 30528, 128)])
+def test_multi_round_launches(layout, tile, shape):
+    """More tiles than CUs of one problem (several rounds of workgroups per CU): ragged edges in both dimensions, bias."""
+    from kvq import nnops
+    M, N, K = shape
+    a, b, ref = _ops(layout, M, N, K, seed=M + N + K)
+    bias = torch.randn(N, device="cuda").to(torch.bfloat16)
+    big = torch.full((M + 1, N + 24), 3.0, device="cuda", dtype=torch.bfloat16)
+    out = big[:M, 8:8 + N]
+    nnops.gemm(a, b, layout, bias=bias, out=out, tile=tile)
+    _check(out, ref + bias.float(), K)
+    assert (big[M] == 3).all() and (big[:, :8] == 3).all() and (big[:, 8 + N:] == 3).all()
+    out2 = nnops.gemm(a, b, layout, bias=bias, tile=tile)          # same launch again: bitwise reproducible
+    assert torch.equal(out2, out)
