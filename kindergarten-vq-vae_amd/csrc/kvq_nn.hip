@@ -1614,7 +1614,10 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
 }
 
 __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned Kt[16 * AM_LDT], Qt[16 * AM_LDT], Gt[16 * AM_LDT];
+    // ONE pair-interleaved staging tile, used for K, then Q, then dO (their row chunks stay in registers): 10 KiB of LDS per
+    // (sentence, head) instead of 19 KiB, so that all B * nh waves of a step-sized launch (3072 at bert-base, 12 per CU) are
+    // resident at once -- with three tiles the LDS admitted 8 per CU and the launch ran one and a half rounds of a latency-bound kernel
+    __shared__ __attribute__((aligned(16))) unsigned Xt[16 * AM_LDT];
     __shared__ __attribute__((aligned(16))) unsigned TD[AT_S * AM_LDX], TP[AT_S * AM_LDX];
     __shared__ __attribute__((aligned(16))) float Wv[3 * AT_S];
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
@@ -1632,9 +1635,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     for (int s = 0; s < 4; ++s) accS = mfma32(kf[s], qf[s], accS);     // S^T[key][query]
 #pragma unroll
     for (int s = 0; s < 4; ++s) accP = mfma32(vf[s], gf[s], accP);     // dP~^T[key][query] = V[key] . dO[query]
-    stage_pairs_from_chunks(Kt, r, h, kf);
-    stage_pairs_from_chunks(Qt, r, h, qf);
-    stage_pairs_from_chunks(Gt, r, h, gf);
+    stage_pairs_from_chunks(Xt, r, h, kf);
     float s[16], dp[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) { s[v] = accS[v]; dp[v] = accP[v]; }
@@ -1668,7 +1669,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     for (int dt = 0; dt < 2; ++dt) {                        // dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
         f32x16 o = zero16();
 #pragma unroll
-        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<1>(Kt, 32 * dt + r, h, st), dsf[st], o);
+        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<1>(Xt, 32 * dt + r, h, st), dsf[st], o);
         if (qvalid) store_ct(p.g_q, ((size_t)b * p.Sq + r) * p.ldq + hd * AT_D, h, 32 * dt, o);
     }
     uint4 tdf[2], tpf[2];                                   // lane = key r: dS[query 16st + 8h + t][r], P~[..][r]
@@ -1677,18 +1678,9 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
         tdf[st] = *reinterpret_cast<const uint4*>(TD + r * AM_LDX + 8 * st + 4 * h);
         tpf[st] = *reinterpret_cast<const uint4*>(TP + r * AM_LDX + 8 * st + 4 * h);
     }
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {                        // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key];  dV^T = dO^T . P~
-        f32x16 o = zero16();
-#pragma unroll
-        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<0>(Qt, 32 * dt + r, h, st), tdf[st], o);
-        if (kvalid) store_ct(p.g_k, ((size_t)b * p.Sk + r) * p.ldk + hd * AT_D, h, 32 * dt, o);
-        o = zero16();
-#pragma unroll
-        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<0>(Gt, 32 * dt + r, h, st), tpf[st], o);
-        if (kvalid) store_ct(p.g_v, ((size_t)b * p.Sk + r) * p.ldv + hd * AT_D, h, 32 * dt, o);
-    }
-    if (p.pb_q || p.pb_k || p.pb_v) {                       // wave-uniform
+    const bool partials = p.pb_q || p.pb_k || p.pb_v;       // wave-uniform
+    const size_t col = (size_t)hd * AT_D + 32 * h + r;
+    if (partials) {
         // column sums over this sentence of the three gradients = bias-gradient partials of the q / k / v projections:
         //   sum_q dQ[q][d] = sum_key K[key][d] cs[key],  cs[key] = sum_q dS[q][key]     (from the transposed image, lane = key)
         //   sum_k dK[k][d] = sum_q   Q[q][d]   rs[q],    rs[q]   = sum_key dS[q][key]   (lane-local)
@@ -1705,11 +1697,30 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
         rs += __shfl_xor(rs, 32, WAVE); rp += __shfl_xor(rp, 32, WAVE); cs += __shfl_xor(cs, 32, WAVE);
         if (h == 0) { Wv[r] = cs; Wv[32 + r] = rs; Wv[64 + r] = rp; }
         __syncthreads();
-        const size_t col = (size_t)hd * AT_D + 32 * h + r;
-        if (p.pb_q) p.pb_q[(size_t)b * p.ldp_q + col] = weighted_colsum(Kt, Wv, r, h);
-        if (p.pb_k) p.pb_k[(size_t)b * p.ldp_kv + col] = weighted_colsum(Qt, Wv + 32, r, h);
-        if (p.pb_v) p.pb_v[(size_t)b * p.ldp_kv + col] = weighted_colsum(Gt, Wv + 64, r, h);
+        if (p.pb_q) p.pb_q[(size_t)b * p.ldp_q + col] = weighted_colsum(Xt, Wv, r, h);
     }
+    __syncthreads();                                        // every read of the K tile is done: the tile becomes Q
+    stage_pairs_from_chunks(Xt, r, h, qf);
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {                        // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+        f32x16 o = zero16();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<0>(Xt, 32 * dt + r, h, st), tdf[st], o);
+        if (kvalid) store_ct(p.g_k, ((size_t)b * p.Sk + r) * p.ldk + hd * AT_D, h, 32 * dt, o);
+    }
+    if (partials && p.pb_k) p.pb_k[(size_t)b * p.ldp_kv + col] = weighted_colsum(Xt, Wv + 32, r, h);
+    __syncthreads();                                        // ... and now dO
+    stage_pairs_from_chunks(Xt, r, h, gf);
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {                        // dV^T[d][key] = sum_q dO^T[d][q] P~[q][key]
+        f32x16 o = zero16();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<0>(Xt, 32 * dt + r, h, st), tpf[st], o);
+        if (kvalid) store_ct(p.g_v, ((size_t)b * p.Sk + r) * p.ldv + hd * AT_D, h, 32 * dt, o);
+    }
+    if (partials && p.pb_v) p.pb_v[(size_t)b * p.ldp_kv + col] = weighted_colsum(Xt, Wv + 64, r, h);
 }
 
 }  // namespace kvq
