@@ -246,12 +246,12 @@ int kvq_attn_set_variant(int variant);
  * bf16 operands and result, f32 accumulation (v_mfma_f32_16x16x32_bf16), optional bias[N] (bf16) and C += (accumulate != 0).
  * K %% 64 == 0; M, N, lda, ldb, ldc %% 8 == 0; 16-byte aligned operands; row-major with the given leading dimensions.
  * `tile` picks the workgroup tile: the caller chooses it so that the tile count fills the 256 CUs.
- * A grouped launch runs up to 8 problems of ONE layout as a single grid (e.g. the four weight gradients of a BERT layer:
- * ~250 tiles of 128 x 256, one per CU over the whole token contraction -- no split-K, no partial slabs). */
+ * A grouped launch runs up to 16 problems of ONE layout as a single grid (e.g. the weight gradients of two BERT layers:
+ * ~250 tiles of 256 x 256, one per CU over the whole token contraction -- no split-K, no partial slabs). */
 #define KVQ_GEMM_NT 0
 #define KVQ_GEMM_NN 1
 #define KVQ_GEMM_TN 2
-#define KVQ_GEMM_TILE_128x192 0   /* 4 waves; 256 tiles for [8192, 768] outputs */
+#define KVQ_GEMM_TILE_128x192 0   /* 8 waves; 256 tiles for [8192, 768] outputs */
 #define KVQ_GEMM_TILE_128x256 1   /* 8 waves */
 #define KVQ_GEMM_TILE_256x192 2   /* 8 waves */
 #define KVQ_GEMM_TILE_256x256 3   /* 8 waves */

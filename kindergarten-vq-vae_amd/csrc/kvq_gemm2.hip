@@ -39,7 +39,7 @@ typedef __attribute__((address_space(3))) s16x4* l4ptr_t;
 
 constexpr int BK = 64;                 // k-tile depth
 constexpr int ROWB = 128;              // bytes per LDS row
-constexpr int MAX_PROBLEMS = 8;
+constexpr int MAX_PROBLEMS = 16;
 
 struct Problem {
     const unsigned short* A;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_f8_kernel(Para
 //                 BM   BN  WM WN  A k-major  B k-major  ring
 template <bool AK, bool BKM> using Cfg128x256 = Cfg<128, 256, 2, 4, AK, BKM, 3>;     // 8 waves, 144 KiB: one tile per CU (wgrad)
 template <bool AK, bool BKM> using Cfg256x192 = Cfg<256, 192, 4, 2, AK, BKM, 2>;     // 8 waves, 112 KiB
-template <bool AK, bool BKM> using Cfg128x192 = Cfg<128, 192, 2, 2, AK, BKM, 3>;     // 4 waves, 120 KiB: 256 tiles at N = 768
+template <bool AK, bool BKM> using Cfg128x192 = Cfg<128, 192, 2, 4, AK, BKM, 3>;     // 8 waves, 120 KiB: 256 tiles at N = 768
 template <bool AK, bool BKM> using Cfg256x256 = Cfg<256, 256, 2, 4, AK, BKM, 2>;     // 8 waves, 128 KiB
 
 template <class C, int EPI = EPI_NONE>

@@ -268,6 +268,7 @@ class TrainEngine:
         # weight gradients of a whole layer as ONE grouped launch of csrc/kvq_gemm2.hip (KVQ_OWN_WGRAD=0: library + split-K slabs)
         self._own_wgrad = self._own_fwd and os.environ.get("KVQ_OWN_WGRAD", "1") != "0" and self.dtype == torch.bfloat16
         self._wg_items, self._wg_keep = [], []
+        self._wg_pair = os.environ.get("KVQ_WG_PAIR", "1") != "0"     # A/B switch: 0 = one grouped launch per layer (128 x 256 tiles)
         # opt-in (KVQ_WG_STREAM=1): weight-gradient GEMMs on a side stream.  Measured on MI355X with the step replayed from
         # hipGraphs: 23.6 ms/step against 22.5 ms on one stream -- two concurrent hipBLASLt kernels share CUs and L2 badly
         self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get("KVQ_WG_STREAM", "0") == "1" else None
@@ -394,7 +395,7 @@ class TrainEngine:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
         self._avg_in_comm = self.world > 1 and dist.get_backend(process_group) == "nccl"   # RCCL averages itself; gloo sums
         self.chunk = max(bucket_mib * (1 << 20) // self.flat.grad.element_size(), 1 << 16)     # elements per all-reduce chunk
-        self._pending_hi = self.flat.n
+        self._pending_hi = self._wg_done_lo = self.flat.n
         self._works, self._works_late = [], []
         self._ev_early = torch.cuda.Event() if self.world > 1 else None
         self._time_comm = False
@@ -427,9 +428,9 @@ class TrainEngine:
 
     # (N, K) -> workgroup tile of csrc/kvq_gemm2.hip for the shapes where it beats the tuned library at 8192 rows
     # (tools/gemm2_probe.py on MI355X, interleaved rounds; gpurun_out/g2_probe*.log); every other shape stays with hipBLASLt
-    _OWN_FWD = {(768, 768): "128x256"}                                          # y = x . W^T + b        ("nt")
-    _OWN_DGRAD = {(768, 768): "128x256", (768, 2304): "128x256", (768, 3072): "128x256", (3072, 768): "256x192",
-                  (768, 18432): "128x256"}                                      # gx = gy . W            ("nn")
+    _OWN_FWD = {(768, 768): "128x192", (768, 3072): "128x192"}                  # y = x . W^T + b        ("nt")
+    _OWN_DGRAD = {(768, 768): "128x192", (768, 2304): "128x192", (768, 3072): "128x192", (3072, 768): "256x192",
+                  (768, 18432): "128x192"}                                      # gx = gy . W            ("nn")
     # BertIntermediate / its backward with the activation inside the GEMM epilogue: (N, K) -> tile
     # Measured on MI355X (tools/gemm2_probe.py epi): the fused kernels TIE with GEMM + separate activation kernel (FFN1 forward
     # 66.1 vs 47.5 + 19.3 us, FFN2 backward 79.5 vs 47.1 + 29.8 us) -- the exact-erf VALU work (two transcendentals per
@@ -542,23 +543,39 @@ class TrainEngine:
         self._red_items.append(nnops.reduce_item(src, dst, count, cols, ld, src_offset=src_offset))
         self._red_keep.append(src)            # the partials must outlive the launch
 
-    def _flush_wgrads(self):
-        """The weight gradients queued since the last flush (one layer's worth) as one grouped launch: ~250 tiles of 128 x 256,
-        one per CU over the whole token contraction, written straight into the flat bf16 gradient buffer."""
+    _WG_MAX = 16                                          # problems per grouped launch (csrc/kvq_gemm2.hip MAX_PROBLEMS)
+
+    @staticmethod
+    def _wg_tiles(items, bm, bn):
+        return sum(-(-p.M // bm) * -(-p.N // bn) for p in items)
+
+    def _flush_wgrads(self, force=True):
+        """The weight gradients queued so far as grouped launches, written straight into the flat bf16 gradient buffer, each
+        tile contracting over all tokens (no split-K).  The kernel's rate is set by bytes staged per flop (the L2 -> LDS fill
+        is the limit), so the 256 x 256 tile is the fast one -- but one BERT layer is only 108-126 of them.  The
+        queue is therefore held (force=False) until TWO layers' worth is there: 216-252 tiles = one round of the 256 CUs.
+        Returns True when nothing is left queued."""
         items = self._wg_items
+        if not items:
+            return True
+        t256 = self._wg_tiles(items, 256, 256)
+        if not force and self._wg_pair and self.wg_stream is None and len(items) <= self._WG_MAX // 2 and 2 * t256 <= 256:
+            return False                                   # another layer like this one still fits the same round
+        tile = "256x256" if self._wg_tiles(items, 128, 256) > 256 and t256 <= 320 else "128x256"
         if self.wg_stream is not None:
             # KVQ_WG_STREAM=1: the layer's weight gradients run on a side stream while the main stream goes on with the next
             # layer's backward chain (nothing there reads them); joined at the end of backward / before an all-reduce
             self.wg_stream.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(self.wg_stream):
-                for i in range(0, len(items), 8):
-                    nnops.gemm_grouped(items[i:i + 8], "tn", "128x256")
+                for i in range(0, len(items), self._WG_MAX):
+                    nnops.gemm_grouped(items[i:i + self._WG_MAX], "tn", tile)
             self._wg_pending = True
             self._wg_keep_step += self._wg_keep            # operands stay alive until the join
         else:
-            for i in range(0, len(items), 8):
-                nnops.gemm_grouped(items[i:i + 8], "tn", "128x256")
+            for i in range(0, len(items), self._WG_MAX):
+                nnops.gemm_grouped(items[i:i + self._WG_MAX], "tn", tile)
         self._wg_items, self._wg_keep = [], []
+        return True
 
     def _join_wgrads(self):
         if self._wg_pending:
@@ -566,12 +583,13 @@ class TrainEngine:
             self._wg_pending = False
         self._wg_keep_step = []
 
-    def _flush_reductions(self):
-        if self._wg_items:
-            self._flush_wgrads()
+    def _flush_reductions(self, force=True):
+        """Launch the queued batched reductions and (see _flush_wgrads) the queued weight gradients; True if none stay queued."""
+        done = self._flush_wgrads(force)
         if self._red_items:
             nnops.reduce_batch(self._red_items)
         self._red_items, self._red_keep = [], []
+        return done
 
     def _defer_colsum(self, x, dst, cols=None):
         part = nnops.colsum_partial(x, cols)
@@ -813,11 +831,14 @@ class TrainEngine:
     def _grads_done_down_to(self, name, partial=False):
         """Every gradient located at or after segment `name` is final (once the queued reductions have been launched).
         `partial`: also send the incomplete chunk above `name` (used before the last, late part of backward)."""
-        self._flush_reductions()
+        lo = self.flat.seg[name][0]
+        if not self._flush_reductions(force=partial):
+            lo = self._wg_done_lo                          # weight gradients of this layer still queued: final only above there
+        else:
+            self._wg_done_lo = lo
         if self.world == 1:
             return
         self._join_wgrads()
-        lo = self.flat.seg[name][0]
         while self._pending_hi - self.chunk >= lo:
             self._reduce(self._pending_hi - self.chunk, self._pending_hi)
             self._pending_hi -= self.chunk
@@ -1217,6 +1238,7 @@ class TrainEngine:
             cut = self._pending_hi                    # [0, cut) has not been sent yet (embedding gradients)
             self._eager(lambda: self._exchange_head(cut))
             self._pending_hi = fl.n
+        self._wg_done_lo = fl.n
         if self.vq_ema:          # the codebook follows the EMA of its assigned encoder outputs (backward has used the old one by now)
             self._eager(self._ema_step)
         self._step_host += 1
@@ -1307,6 +1329,7 @@ class TrainEngine:
             except Exception:
                 self._works, self._works_late = [], []
             self._pending_hi = self.flat.n
+        self._wg_done_lo = self.flat.n
         self._red_items, self._red_keep, self._wg_pending = [], [], False
         self._wg_items, self._wg_keep, self._wg_keep_step = [], [], []
 

@@ -272,7 +272,7 @@ def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
 
 
 def gemm_grouped(problems, layout, tile):
-    """One launch over a list of gemm_problem()s of one layout (at most 8)."""
+    """One launch over a list of gemm_problem()s of one layout (at most 16)."""
     from ._ffi import GemmProblem
     arr = (GemmProblem * len(problems))(*problems)
     t = TILES[tile] if isinstance(tile, str) else tile

@@ -92,6 +92,26 @@ def test_grouped_weight_gradients_of_one_layer(tile):
         _check(outs[3 * i], r, T)
 
 
+def test_grouped_weight_gradients_of_two_decoder_layers():
+    """The engine's default launch: twelve TN problems (two decoder layers) as 252 tiles of 256 x 256; 17 problems are refused."""
+    from kvq import nnops
+    from kvq._ffi import KvqError
+    T = 512
+    g = torch.Generator(device="cuda").manual_seed(2)
+    probs, outs, refs, keep = [], [], [], []
+    for (m, n) in [(2304, 768), (768, 768), (768, 768), (768, 768), (3072, 768), (768, 3072)] * 2:
+        gy = torch.randn((T, m), generator=g, device="cuda").to(torch.bfloat16)
+        x = torch.randn((T, n), generator=g, device="cuda").to(torch.bfloat16)
+        out = torch.empty((m, n), device="cuda", dtype=torch.bfloat16)
+        probs.append(nnops.gemm_problem(gy, x, out, "tn"))
+        outs.append(out); refs.append(gy.float().t() @ x.float()); keep += [gy, x]
+    nnops.gemm_grouped(probs, "tn", "256x256")
+    for o, r in zip(outs, refs):
+        _check(o, r, T)
+    with pytest.raises(KvqError):
+        nnops.gemm_grouped((probs * 2)[:17], "tn", "256x256")
+
+
 def test_gemm_rejects_bad_arguments():
     from kvq import nnops
     from kvq._ffi import KvqError
