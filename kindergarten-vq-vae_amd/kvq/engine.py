@@ -431,13 +431,12 @@ class TrainEngine:
     _OWN_FWD = {(768, 768): "128x192", (768, 3072): "128x192"}                  # y = x . W^T + b        ("nt")
     _OWN_DGRAD = {(768, 768): "128x192", (768, 2304): "128x192", (768, 3072): "128x192", (3072, 768): "256x192",
                   (768, 18432): "128x192"}                                      # gx = gy . W            ("nn")
-    # BertIntermediate / its backward with the activation inside the GEMM epilogue: (N, K) -> tile
-    # Measured on MI355X (tools/gemm2_probe.py epi): the fused kernels TIE with GEMM + separate activation kernel (FFN1 forward
-    # 66.1 vs 47.5 + 19.3 us, FFN2 backward 79.5 vs 47.1 + 29.8 us) -- the exact-erf VALU work (two transcendentals per
-    # element) runs behind the MFMA loop of a one-workgroup-per-CU kernel instead of beside it -- so they stay opt-in
-    # (KVQ_OWN_GELU / KVQ_OWN_DGELU = "3072x768:256x192").
-    _OWN_GELU = {}                                                              # (h, gelu(h)) = x . W^T + b
-    _OWN_DGELU = {}                                                             # (gy . W) * gelu'(h) + bias-gradient partials
+    # BertIntermediate / its backward with the activation inside the GEMM epilogue: (N, K) -> tile.  One v_exp_f32 + one v_rcp_f32
+    # per element (Phi and phi share the exponential) and packed f32 FMAs; measured on MI355X (tools/gemm2_probe.py epi):
+    # FFN1 forward 57.7 us against 44.5 + 19.3 (GEMM + gelu kernel), FFN2 backward 65.6 against 45.3 + 29.8; in the step
+    # 19.07 -> 18.58 ms (gpurun_out/ab5.log).  KVQ_OWN_GELU="" / KVQ_OWN_DGELU="" switch back to the separate kernels.
+    _OWN_GELU = {(3072, 768): "256x192"}                                        # (h, gelu(h)) = x . W^T + b
+    _OWN_DGELU = {(3072, 768): "256x192"}                                       # (gy . W) * gelu'(h) + bias-gradient partials
     _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "256x192"}      # gW = gy^T . x          ("tn"), own launch
 
     # ---- fp8 forward GEMMs -------------------------------------------------------------------------------------------------
@@ -524,7 +523,8 @@ class TrainEngine:
     def _linear_gelu(self, x, wname, bname):
         """(h, gelu(h)), h = x . W^T + b: one kernel where the own GEMM carries the activation in its epilogue."""
         W, b = self.flat.w(wname), self.flat.w(bname)
-        tile = self._OWN_GELU.get(tuple(W.shape)) if self._own_fwd and self.dtype == torch.bfloat16 and x.shape[0] >= 2048 else None
+        tile = self._OWN_GELU.get(tuple(W.shape)) if self._own_fwd and self.dtype == torch.bfloat16 and x.shape[0] >= 2048 \
+            and not self.fp8 else None               # (fp8 forward: the fp8 GEMM + the activation kernel)
         if tile is not None and x.is_contiguous():
             return nnops.gemm_gelu(x, W, b, tile=tile)
         h = self._linear(x, wname, bname)
