@@ -314,6 +314,9 @@ int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void
  * kvq_step_state_advance   one-thread kernel run at the start of an optimiser step: step += 1, lr = lr0 * gamma^(number of
  *                          milestones <= step-1)  (torch MultiStepLR ticked once per finished step, Trainer.py:114-115),
  *                          bc1 = 1 - beta1^step, bc2s = sqrt(1 - beta2^step).  At most 8 milestones (host array).
+ * kvq_step_state_prepare / _commit   the two halves of _advance: prepare writes lr / bc1 / bc2s of the step about to be applied
+ *                          and leaves `step` (the dropout seed offset) alone, commit does step += 1.  For an optimiser whose
+ *                          updates start while backward -- which still recomputes this step's dropout masks -- is running.
  * kvq_adam_step_dev        kvq_adam_step reading lr / bias corrections from the step state instead of taking them by value.
  * kvq_set_seed_offset      library-wide: every dropout-bearing kernel launched afterwards (kvq_dropout,
  *                          kvq_dropout_residual_ln_*, kvq_attn_*) uses seed + step_state->step, read on the device at run
@@ -323,6 +326,9 @@ int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void
  *                          other kernels.  Forward and (applied to the gradient) backward of a plain dropout.  n %% 4 == 0. */
 int kvq_step_state_advance(void* step_state, float lr0, float gamma, const int64_t* milestones, int n_milestones, float beta1,
                            float beta2, void* stream);
+int kvq_step_state_prepare(void* step_state, float lr0, float gamma, const int64_t* milestones, int n_milestones, float beta1,
+                           float beta2, void* stream);
+int kvq_step_state_commit(void* step_state, void* stream);
 int kvq_adam_step_dev(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
                       const void* step_state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                       void* stream);

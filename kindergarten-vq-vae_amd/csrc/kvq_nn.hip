@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
 
 // backward: g_pre = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  g_resid = g_pre;
 //           g_y = g_pre * dropout_mask/(1-p);  dgamma/dbeta partials per workgroup (summed by colsum_final_kernel)
-constexpr int LNB_ROWS = 8;    // rows per workgroup (4 waves x 2 rows): 1024 workgroups at N = 8192
+constexpr int LNB_ROWS = 16;   // rows per workgroup (4 waves x 4 rows, all in flight at once): 512 workgroups and 512 partial rows at N = 8192
 
 template <int DT, int PER>
 __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ g_out, const void* __restrict__ pre,
@@ -604,16 +604,19 @@ struct Milestones {
     long long at[8];
     int n;
 };
-__global__ void step_state_advance_kernel(StepState* st, float lr0, float gamma, Milestones ms, float beta1, float beta2) {
+// phase 1: lr / bias corrections of the step about to be applied; phase 2: step += 1; 3: both (kvq_step_state_advance)
+__global__ void step_state_advance_kernel(StepState* st, float lr0, float gamma, Milestones ms, float beta1, float beta2, int phase) {
     const unsigned long long t = st->step + 1;             // the step now being applied (1-based)
-    int k = 0;
-    for (int i = 0; i < ms.n; ++i) k += ((long long)(t - 1) >= ms.at[i]) ? 1 : 0;   // MultiStepLR ticked once per finished step
-    double lr = lr0;
-    for (int i = 0; i < k; ++i) lr *= (double)gamma;
-    st->lr = (float)lr;
-    st->bc1 = (float)(1.0 - pow((double)beta1, (double)t));
-    st->bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)t));
-    st->step = t;
+    if (phase & 1) {
+        int k = 0;
+        for (int i = 0; i < ms.n; ++i) k += ((long long)(t - 1) >= ms.at[i]) ? 1 : 0;   // MultiStepLR ticked once per finished step
+        double lr = lr0;
+        for (int i = 0; i < k; ++i) lr *= (double)gamma;
+        st->lr = (float)lr;
+        st->bc1 = (float)(1.0 - pow((double)beta1, (double)t));
+        st->bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    }
+    if (phase & 2) st->step = t;
 }
 
 // out = x * keep / (1-p) with the Philox mask of (seed, site): the dropout behind the embedding LayerNorm (modeling_bert.py:58,
@@ -1960,15 +1963,27 @@ int kvq_adam_step_dev(float* p, const void* g, float* m, float* v, float* vmax, 
                        reinterpret_cast<const float*>(reinterpret_cast<const char*>(step_state) + 8), stream);
 }
 
-int kvq_step_state_advance(void* step_state, float lr0, float gamma, const int64_t* milestones, int n_milestones, float beta1,
-                           float beta2, void* stream) {
+static int step_state_launch(void* step_state, float lr0, float gamma, const int64_t* milestones, int n_milestones, float beta1,
+                             float beta2, int phase, void* stream, const char* who) {
     KVQ_REQUIRE(step_state && n_milestones >= 0 && n_milestones <= 8 && (n_milestones == 0 || milestones),
-                "kvq_step_state_advance: bad argument (at most 8 milestones)");
+                "%s: bad argument (at most 8 milestones)", who);
     Milestones ms = {};
     ms.n = n_milestones;
     for (int i = 0; i < n_milestones; ++i) ms.at[i] = milestones[i];
-    hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (StepState*)step_state, lr0, gamma, ms, beta1, beta2);
+    hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (StepState*)step_state, lr0, gamma, ms, beta1,
+                       beta2, phase);
     return check_launch("step_state_advance_kernel");
+}
+int kvq_step_state_advance(void* step_state, float lr0, float gamma, const int64_t* milestones, int n_milestones, float beta1,
+                           float beta2, void* stream) {
+    return step_state_launch(step_state, lr0, gamma, milestones, n_milestones, beta1, beta2, 3, stream, "kvq_step_state_advance");
+}
+int kvq_step_state_prepare(void* step_state, float lr0, float gamma, const int64_t* milestones, int n_milestones, float beta1,
+                           float beta2, void* stream) {
+    return step_state_launch(step_state, lr0, gamma, milestones, n_milestones, beta1, beta2, 1, stream, "kvq_step_state_prepare");
+}
+int kvq_step_state_commit(void* step_state, void* stream) {
+    return step_state_launch(step_state, 0.f, 0.f, nullptr, 0, 0.f, 0.f, 2, stream, "kvq_step_state_commit");
 }
 
 size_t kvq_embed_grad_workspace_bytes(int64_t N, int H) {

@@ -92,6 +92,8 @@ SIGNATURES = {
     "kvq_attn_set_variant": (_int, [_int]),
     "kvq_adam_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "kvq_step_state_advance": (_int, [_vp, _f32, _f32, C.POINTER(_i64), _int, _f32, _f32, _vp]),
+    "kvq_step_state_prepare": (_int, [_vp, _f32, _f32, C.POINTER(_i64), _int, _f32, _f32, _vp]),
+    "kvq_step_state_commit": (_int, [_vp, _vp]),
     "kvq_adam_step_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _f32, _f32, _f32, _f32, _f32, _vp]),
     "kvq_set_seed_offset": (_int, [_vp]),
     "kvq_embed_grad_workspace_bytes": (_sz, [_i64, _int]),

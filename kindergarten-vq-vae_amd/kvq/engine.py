@@ -188,7 +188,7 @@ class _StepGraphs:
                 # thread-local capture mode: the process group's helper threads (gloo copies, the RCCL watchdog's event queries)
                 # keep issuing HIP calls on their own streams while this thread captures
                 self.graphs[0].capture_begin(capture_error_mode="thread_local")
-                self.out = eng.forward_backward(self.ids, self.mask, training=eng.model.training, compute_grads=True)
+                self.out = eng.forward_backward(self.ids, self.mask, training=eng.model.training, compute_grads=True, fuse_optimizer=True)
                 eng.optimizer_step()
                 self.graphs[-1].capture_end()
                 ok = True
@@ -197,6 +197,7 @@ class _StepGraphs:
                 eng._step_host = step0      # capturing ran no captured kernel: the device step state did not move either
                 if not ok:                  # close the capture that was open when the error struck
                     try:
+                        eng._adam_join()    # (a forked side stream must be back in the origin stream before the capture can end)
                         self.graphs[-1].capture_end()
                     except Exception:
                         pass
@@ -269,6 +270,14 @@ class TrainEngine:
         self._own_wgrad = self._own_fwd and os.environ.get("KVQ_OWN_WGRAD", "1") != "0" and self.dtype == torch.bfloat16
         self._wg_items, self._wg_keep = [], []
         self._wg_pair = os.environ.get("KVQ_WG_PAIR", "1") != "0"     # A/B switch: 0 = one grouped launch per layer (128 x 256 tiles)
+        # opt-in (KVQ_EARLY_ADAM=1): Adam for a layer's parameters as soon as their gradients are final, on a side stream beside the
+        # rest of backward (one GPU only).  The update is pure HBM streaming and the GEMMs beside it live on L2 -> LDS bandwidth,
+        # yet on MI355X the step got SLOWER: 18.88 against 18.18 ms (gpurun_out/ab6.log), and 19.5-19.8 against 18.86 with the
+        # Adam grid capped at 128-1024 workgroups (ab7.log) -- like the side-stream weight gradients, a second kernel on the
+        # CUs costs the one-workgroup-per-CU GEMMs more than the overlap returns.  Off by default.
+        self._early_adam = os.environ.get("KVQ_EARLY_ADAM", "0") == "1"
+        self.adam_stream = torch.cuda.Stream(device=dev) if self._early_adam else None
+        self._fuse_opt, self._adam_hi, self._adam_forked = False, 0, False
         # opt-in (KVQ_WG_STREAM=1): weight-gradient GEMMs on a side stream.  Measured on MI355X with the step replayed from
         # hipGraphs: 23.6 ms/step against 22.5 ms on one stream -- two concurrent hipBLASLt kernels share CUs and L2 badly
         self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get("KVQ_WG_STREAM", "0") == "1" else None
@@ -837,6 +846,9 @@ class TrainEngine:
         else:
             self._wg_done_lo = lo
         if self.world == 1:
+            if self._fuse_opt and lo < self._adam_hi:
+                self._adam_early(lo, self._adam_hi)
+                self._adam_hi = lo
             return
         self._join_wgrads()
         while self._pending_hi - self.chunk >= lo:
@@ -857,6 +869,7 @@ class TrainEngine:
 
     def _eager(self, fn):
         """Run fn now; while a step is being captured it also becomes an eager launch between two graphs of the replay."""
+        self._adam_join()                  # a captured graph ends here: no side-stream work may be left open in it
         if self._cap is not None:
             self._cap.interlude(fn)
         else:
@@ -919,9 +932,12 @@ class TrainEngine:
     # one training step
     # ------------------------------------------------------------------------------------------------------------
     def forward_backward(self, input_ids, attention_mask, training=True, compute_grads=True, dec_ids=None, dec_mask=None,
-                         want_logits=False, quantizer_training=None):
+                         want_logits=False, quantizer_training=None, fuse_optimizer=False):
         """Forward (+ backward when compute_grads).  Returns dict(loss_recon, loss_vq, perplexity, acc, recon_ids, indices
-        [, logits]).  dec_ids / dec_mask: the decoder's own input (Bagon.forward takes one; default = the encoder's)."""
+        [, logits]).  dec_ids / dec_mask: the decoder's own input (Bagon.forward takes one; default = the encoder's).
+        fuse_optimizer (train_step only; optimizer_step() MUST follow): parameters are updated while backward still runs."""
+        self._fuse_opt = bool(fuse_optimizer) and compute_grads and self._early_adam and self.world == 1
+        self._adam_hi, self._adam_forked = self.flat.n, False
         S = max(input_ids.shape[1], dec_ids.shape[1] if dec_ids is not None else 0)
         if S > 32:
             raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
@@ -1026,6 +1042,8 @@ class TrainEngine:
             return out
 
         # ---------------- backward ----------------
+        if self._fuse_opt:      # lr / bias corrections of the step about to be applied; the step COUNT (dropout seed offset) stays
+            nnops.step_state_advance(self._state, self.lr, self.gamma, self.milestones, self.betas[0], self.betas[1], phase="prepare")
         tr = fl.trainable
         g_scale = self._ones * self.w_recon
         if tr["head.bias"] and self.Vp % 8 == 0:
@@ -1230,9 +1248,35 @@ class TrainEngine:
                                     vmax=fl.vmax[a:b] if fl.vmax is not None else None,
                                     shadow=fl.shadow[a:b] if fl.shadow is not fl.master else None)
 
+    def _adam_early(self, lo, hi):
+        """[lo, hi) of the flat buffer is final and no kernel of this step reads those weights any more: update it beside backward."""
+        main = torch.cuda.current_stream(self.dev)
+        self.adam_stream.wait_stream(main)
+        with torch.cuda.stream(self.adam_stream):
+            self._adam_ranges(lo, hi)
+        self._adam_forked = True
+
+    def _adam_join(self):
+        if self._adam_forked:
+            torch.cuda.current_stream(self.dev).wait_stream(self.adam_stream)
+            self._adam_forked = False
+
     def optimizer_step(self):
         fl = self.flat
         b1, b2 = self.betas
+        if self._fuse_opt:
+            self._fuse_opt = False
+            self._wg_done_lo = fl.n
+            if self.vq_ema:
+                self._eager(self._ema_step)
+            self._step_host += 1
+            self._adam_ranges(0, self._adam_hi)           # the head of the buffer: embeddings, final only now
+            self._adam_hi = fl.n
+            self._adam_aux()
+            self._adam_join()
+            nnops.step_state_commit(self._state)
+            self._after_update()
+            return
         cut = 0
         if self.world > 1:
             cut = self._pending_hi                    # [0, cut) has not been sent yet (embedding gradients)
@@ -1248,15 +1292,21 @@ class TrainEngine:
         if self.world > 1:
             self._eager(self._exchange_tail)
             self._adam_ranges(0, cut)
+        self._adam_aux()
+        self._after_update()
+
+    def _adam_aux(self):
+        b1, b2 = self.betas
         for a in self.aux:
             if a["p"].requires_grad:
                 nnops.adam_step_dev(a["p"].data.view(-1), a["g"].view(-1), a["m"].view(-1), a["v"].view(-1), self._state,
                                     b1, b2, self.eps, self.wd, vmax=a["vmax"].view(-1) if a["vmax"] is not None else None)
+
+    def _after_update(self):
         if self.vq_kind in ("VectorQuantizer", "MultiVectorQuantizer") and self.E.requires_grad:
             self._repack_codebook()
         if self.fp8:
             self._fp8_quantize_weights()
-
 
     def _versions(self):
         return sum(p._version for p in self.param_of.values())
@@ -1287,7 +1337,7 @@ class TrainEngine:
             and cfg.hidden_size % 32 == 0 and next(model.parameters()).is_cuda
 
     def _train_step_eager(self, input_ids, attention_mask):
-        out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True)
+        out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True, fuse_optimizer=True)
         self.optimizer_step()
         return out
 
@@ -1332,6 +1382,7 @@ class TrainEngine:
         self._wg_done_lo = self.flat.n
         self._red_items, self._red_keep, self._wg_pending = [], [], False
         self._wg_items, self._wg_keep, self._wg_keep_step = [], [], []
+        self._fuse_opt, self._adam_forked, self._adam_hi = False, False, self.flat.n
 
     def eval_step(self, input_ids, attention_mask):
         return self.forward_backward(input_ids, attention_mask, training=False, compute_grads=False)

@@ -177,12 +177,19 @@ def new_step_state(device):
     return torch.zeros(3, dtype=torch.int64, device=device)
 
 
-def step_state_advance(step_state, lr0, gamma, milestones, beta1, beta2):
+def step_state_advance(step_state, lr0, gamma, milestones, beta1, beta2, phase="advance"):
+    """phase "advance": step += 1 and the lr / bias corrections of that step; "prepare": only the latter (the step counter,
+    which the dropout kernels add to their seed, stays); see step_state_commit()."""
     import ctypes
     ms = [int(x) for x in milestones]
     arr = (ctypes.c_int64 * max(len(ms), 1))(*ms)
-    check(lib().kvq_step_state_advance(step_state.data_ptr(), float(lr0), float(gamma), arr, len(ms), float(beta1), float(beta2),
-                                       stream_ptr()), "kvq_step_state_advance")
+    fn = {"advance": lib().kvq_step_state_advance, "prepare": lib().kvq_step_state_prepare}[phase]
+    check(fn(step_state.data_ptr(), float(lr0), float(gamma), arr, len(ms), float(beta1), float(beta2), stream_ptr()),
+          "kvq_step_state_" + phase)
+
+
+def step_state_commit(step_state):
+    check(lib().kvq_step_state_commit(step_state.data_ptr(), stream_ptr()), "kvq_step_state_commit")
 
 
 def read_step_state(step_state):

@@ -159,6 +159,28 @@ def test_engine_graph_replay_equals_eager_steps():
     assert o1["recon_ids"].shape == o0["recon_ids"].shape and o1["indices"].dtype == torch.int64
 
 
+def test_engine_early_adam_option_equals_the_default_schedule(monkeypatch):
+    """KVQ_EARLY_ADAM=1 (parameters updated on a side stream while backward runs, step state prepared / committed in two
+    halves) must be the same optimiser: losses, step state and parameters after six steps, eager and replayed from graphs."""
+    from kvq import nnops
+    from kvq.engine import TrainEngine
+    batches = [_batch(B=16, S=32, seed=s) for s in (7, 8)]
+    runs = []
+    for early, use_graph in (("0", False), ("1", False), ("1", True)):
+        monkeypatch.setenv("KVQ_EARLY_ADAM", early)
+        model = _build(torch.bfloat16).train()
+        eng = TrainEngine(model, lr=2e-3, milestones=[2], gamma=0.5, seed=17)
+        eng.use_graph = use_graph
+        assert eng._early_adam == (early == "1")
+        losses = [float(eng.train_step(*batches[i % 2])["loss_recon"]) for i in range(6)]
+        runs.append((losses, eng.flat.master.clone(), nnops.read_step_state(eng._state)))
+    for losses, p, st in runs[1:]:
+        np.testing.assert_allclose(np.array(losses), np.array(runs[0][0]), rtol=2e-2, atol=2e-3)
+        assert st == runs[0][2] and st[0] == 6
+        cos = torch.nn.functional.cosine_similarity((p - p.mean()).double(), (runs[0][1] - runs[0][1].mean()).double(), dim=0).item()
+        assert cos > 0.9999, cos
+
+
 def test_engine_step_count_setter_moves_the_device_state():
     from kvq import nnops
     from kvq.engine import TrainEngine

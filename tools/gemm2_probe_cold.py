@@ -64,8 +64,16 @@ def run(name, layout, M, N, K, tiles, pool_bytes=1.5e9):
     print(line, flush=True)
 
 
-for n, k, tl in [(768, 768, ["128x192", "128x256"]), (2304, 768, ["128x192", "256x192", "256x256"]),
+SHAPES = os.environ.get("KVQ_PROBE", "layer")
+for n, k, tl in [] if SHAPES != "layer" else [(768, 768, ["128x192", "128x256"]), (2304, 768, ["128x192", "256x192", "256x256"]),
                  (3072, 768, ["256x192", "256x256", "128x256"]), (768, 3072, ["128x192", "128x256"])]:
     run("fwd", "nt", T, n, k, tl)
-for n, k, tl in [(768, 768, ["128x192"]), (768, 2304, ["128x192"]), (768, 3072, ["128x192"]), (3072, 768, ["256x192", "256x256"])]:
+for n, k, tl in [] if SHAPES != "layer" else [(768, 768, ["128x192"]), (768, 2304, ["128x192"]), (768, 3072, ["128x192"]), (3072, 768, ["256x192", "256x256"])]:
     run("dgrad", "nn", T, n, k, tl)
+if SHAPES == "big":
+    for n in (18432, 30528):
+        run("fwd", "nt", T, n, 768, ["256x256", "256x192"], pool_bytes=2.5e9)
+    for k in (18432, 30528):
+        run("dgrad", "nn", T, 768, k, ["128x192", "128x256"], pool_bytes=2.5e9)
+    for m in (18432, 30528):
+        run("wgrad", "tn", m, 768, T, ["256x256", "256x192"], pool_bytes=2.5e9)

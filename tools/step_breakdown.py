@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Per-step kernel breakdown from a rocprofv3 --kernel-trace CSV of bench.py: the last two steps (between Adam launches).
+usage: step_breakdown.py <dir with *_kernel_trace.csv> [rows]"""
+import collections
+import csv
+import glob
+import sys
+
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+names = [r["Kernel_Name"] for r in rows]
+ad = [i for i, n in enumerate(names) if "adam_kernel<1>" in n]
+a, b = ad[-3], ad[-1]
+tot = collections.defaultdict(lambda: [0, 0])
+for r in rows[a + 1:b + 1]:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    k = r["Kernel_Name"][:78]
+    tot[k][0] += d
+    tot[k][1] += 1
+T = sum(v[0] for v in tot.values()) / 2
+wall = (int(rows[b]["End_Timestamp"]) - int(rows[a]["End_Timestamp"])) / 2e6
+gemm = sum(v[0] for k, v in tot.items() if "gemm2" in k or "Cijk" in k) / 2e6
+own = sum(v[0] for k, v in tot.items() if "gemm2" in k) / 2e6
+print(f"kernel time {T / 1e6:.3f} ms/step, wall {wall:.3f} ms/step, launches {sum(v[1] for v in tot.values()) // 2}, GEMM {gemm:.3f} ms (own {own:.3f})")
+for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])[:top]:
+    print(f"{v[0] / 2e6:7.3f} ms {v[1] // 2:4d} x {v[0] / v[1] / 1000:8.1f} us  {k}")
