@@ -530,6 +530,13 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
 //  256x256 tiles (16-row passes, 16 barriers per tile) 442 vs 357 us.  vmcnt being one in-order queue for loads and stores, the next
 //  tile's first waits also wait for the previous tile's stores, which is most of what the overlap was meant to hide.)
 
+// (Weight gradients -- TN, both operands streamed from HBM, each byte used by 3-12 tiles -- run at 1.0 us per 64-deep k-tile on
+//  128 x 256 and 1.7 us on 256 x 256 with every CU busy (1.17 us with 9 tiles on 9 CUs).  Two attempts to buy that back with a
+//  deeper ring were built, measured and removed in round 2: a 192 x 192 tile with three slots (129 us per encoder layer against
+//  125 for 128 x 256) and 32-deep k-tiles for m-major operands -- five slots for 256 x 256, six for 128 x 256, one barrier per
+//  32 -- which left the two-layer launch at 219 us (221 before) and cost 128 x 256 11 %.  Neither the prefetch distance nor the
+//  bytes per k-tile sets that time; tools/gemm2_probe_wgrad.py is the probe.)
+
 // ---- fp8 (OCP e4m3) operands, NT layout: forward projections of BASELINE.json configs[4] --------------------------------------
 //   C[M,N] (bf16) = (A8[M,K] . B8[N,K]^T) / (sA * sB) + bias,   A8 = sat(x * sA), B8 = sat(W * sB)  (per-tensor scales, on device)
 // Same ring, same LDS images and the same two conflict-free ds_read_b128 per fragment as the bf16 kernel -- a 128-byte LDS row

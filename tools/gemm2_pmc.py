@@ -40,26 +40,38 @@ def both(label, layout, M, N, K, tile):
     torch.cuda.synchronize()
 
 
-for n, k, t in [(768, 768, "128x256"), (2304, 768, "256x192"), (3072, 768, "256x192"), (768, 3072, "128x256"), (18432, 768, "256x256"),
+for n, k, t in [(768, 768, "128x192"), (2304, 768, "128x192"), (3072, 768, "256x192"), (768, 3072, "128x192"), (18432, 768, "256x256"),
                 (30528, 768, "256x256")]:
     both("fwd", "nt", T, n, k, t)
-for n, k, t in [(768, 768, "128x256"), (768, 2304, "128x256"), (768, 3072, "128x256"), (3072, 768, "256x192"), (768, 18432, "128x256"),
-                (768, 30528, "128x256")]:
+for n, k, t in [(768, 768, "128x192"), (768, 2304, "128x192"), (768, 3072, "128x192"), (3072, 768, "256x192"), (768, 18432, "128x192"),
+                (768, 30528, "128x192")]:
     both("dgrad", "nn", T, n, k, t)
-for m, n, t in [(768, 768, "128x256"), (2304, 768, "128x256"), (3072, 768, "128x256"), (768, 3072, "128x256"), (18432, 768, "256x256"),
-                (30528, 768, "256x192")]:
+for m, n, t in [(18432, 768, "256x256"), (30528, 768, "256x192")]:
     both("wgrad", "tn", m, n, T, t)
-# the per-layer grouped weight-gradient launch of the engine (encoder layer: QKV, O, FFN1, FFN2)
-shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)]
+
+
+def own_only(label, who, fn, flops, alg_bytes, layout, M, N, K):
+    fn(); torch.cuda.synchronize()  # noqa: E702
+    mark(dict(label=label, who=who, layout=layout, M=M, N=N, K=K, flops=flops, alg_bytes=alg_bytes))
+    for _ in range(REP):
+        fn()
+    torch.cuda.synchronize()
+
+
+# FFN1 forward with the activation in the epilogue (two outputs), FFN2 input gradient with GELU' and the bias partials
+x, w1, b1 = rnd(T, 768), rnd(3072, 768), rnd(3072)
+own_only("fwd+gelu", "own fused 256x192", lambda: nnops.gemm_gelu(x, w1, b1, tile="256x192"), 2.0 * T * 3072 * 768,
+         2 * (T * 768 + 3072 * 768 + 2 * T * 3072), "nt", T, 3072, 768)
+gf, w2, h = rnd(T, 768), rnd(768, 3072), rnd(T, 3072)
+own_only("dgrad*gelu'", "own fused 256x192", lambda: nnops.gemm_dgelu(gf, w2, h, tile="256x192"), 2.0 * T * 3072 * 768,
+         2 * (T * 768 + 3072 * 768 + 2 * T * 3072), "nn", T, 3072, 768)
+# the engine's grouped weight-gradient launch: TWO encoder layers (QKV, O, FFN1, FFN2 each) as 216 tiles of 256 x 256
+shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072)] * 2
 gys = [rnd(T, m) for m, _ in shapes]; xs = [rnd(T, n) for _, n in shapes]  # noqa: E702
 outs = [torch.empty((m, n), device=dev, dtype=torch.bfloat16) for m, n in shapes]
-probs = [nnops.gemm_problem(g, x, o, "tn") for g, x, o in zip(gys, xs, outs)]
-nnops.gemm_grouped(probs, "tn", "128x256"); torch.cuda.synchronize()  # noqa: E702
-mark(dict(label="wgrad-layer", who="own grouped 128x256", layout="tn", M=6912, N=0, K=T, flops=sum(2.0 * T * m * n for m, n in shapes),
-          alg_bytes=sum(2 * (T * m + T * n + m * n) for m, n in shapes)))
-for _ in range(REP):
-    nnops.gemm_grouped(probs, "tn", "128x256")
-torch.cuda.synchronize()
+probs = [nnops.gemm_problem(g, x_, o, "tn") for g, x_, o in zip(gys, xs, outs)]
+own_only("wgrad-2-layers", "own grouped 256x256", lambda: nnops.gemm_grouped(probs, "tn", "256x256"),
+         sum(2.0 * T * m * n for m, n in shapes), sum(2 * (T * m + T * n + m * n) for m, n in shapes), "tn", 2 * 6912, 0, T)
 mark(dict(label="end", who="", layout="", M=0, N=0, K=0, flops=0, alg_bytes=0))
 out_dir = os.environ.get("KVQ_PMC_PLAN_DIR", "gpurun_out")
 json.dump(plan, open(os.path.join(out_dir, "gemm_pmc_plan.json"), "w"))
