@@ -183,7 +183,7 @@ int kvq_colsum(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, vo
  * the LayerNorm gamma/beta and bias gradients: kvq_*_partial below); run one by one each is a launch-latency-bound kernel.
  * Rows are summed in index order, so results are deterministic.  Long rows with count <= 32 (split-K slabs) take a
  * vectorised path when cols, ld %% 8 == 0 and src/dst are 16-byte aligned. */
-#define KVQ_REDUCE_MAX_ITEMS 16
+#define KVQ_REDUCE_MAX_ITEMS 32
 typedef struct kvq_reduce_item {
     const void* src;
     void* dst;

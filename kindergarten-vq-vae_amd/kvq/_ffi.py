@@ -15,7 +15,7 @@ KVQ_F32, KVQ_BF16 = 0, 1
 
 _vp, _i64, _int, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 
-KVQ_REDUCE_MAX_ITEMS = 16
+KVQ_REDUCE_MAX_ITEMS = 32
 
 
 class ReduceItem(C.Structure):

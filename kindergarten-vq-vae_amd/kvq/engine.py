@@ -270,6 +270,7 @@ class TrainEngine:
         self._own_wgrad = self._own_fwd and os.environ.get("KVQ_OWN_WGRAD", "1") != "0" and self.dtype == torch.bfloat16
         self._wg_items, self._wg_keep = [], []
         self._wg_pair = os.environ.get("KVQ_WG_PAIR", "1") != "0"     # A/B switch: 0 = one grouped launch per layer (128 x 256 tiles)
+        self._red_pair = os.environ.get("KVQ_RED_PAIR", "1") != "0"   # A/B switch: 0 = the batched reductions stay per layer
         # opt-in (KVQ_EARLY_ADAM=1): Adam for a layer's parameters as soon as their gradients are final, on a side stream beside the
         # rest of backward (one GPU only).  The update is pure HBM streaming and the GEMMs beside it live on L2 -> LDS bandwidth,
         # yet on MI355X the step got SLOWER: 18.88 against 18.18 ms (gpurun_out/ab6.log), and 19.5-19.8 against 18.86 with the
@@ -595,6 +596,8 @@ class TrainEngine:
     def _flush_reductions(self, force=True):
         """Launch the queued batched reductions and (see _flush_wgrads) the queued weight gradients; True if none stay queued."""
         done = self._flush_wgrads(force)
+        if not done and self._red_pair:
+            return False                       # ... and the small sums wait with them: one launch per two layers as well
         if self._red_items:
             nnops.reduce_batch(self._red_items)
         self._red_items, self._red_keep = [], []

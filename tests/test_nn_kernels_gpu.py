@@ -131,7 +131,7 @@ def test_reduce_batch_mixed_items(ops):
     assert torch.all(tgt[:8] == 0) and torch.all(tgt[8 + 2 * H:] == 0)
     torch.testing.assert_close(lone, part_ln[:, :H].sum(0), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(out_odd, odd.sum(0), rtol=1e-5, atol=1e-5)
-    many = [ops.reduce_item(slabs_f, torch.empty(100, 44, device=dev), 3, 4400, 4400) for _ in range(37)]   # > 16 items: several launches
+    many = [ops.reduce_item(slabs_f, torch.empty(100, 44, device=dev), 3, 4400, 4400) for _ in range(37)]   # > KVQ_REDUCE_MAX_ITEMS (32): several launches
     ops.reduce_batch(many)
     from kvq import _ffi
     arr = (_ffi.ReduceItem * 17)()
