@@ -5,6 +5,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 run, tag = sys.argv[1], sys.argv[2]
@@ -13,7 +14,7 @@ plan = json.load(open(f"{run}/gemm_pmc_plan.json"))
 
 def groups(pass_name):
     """dispatches of one pass grouped by the marker kernels (FillFunctor<int>) that precede each plan entry"""
-    f = glob.glob(f"{run}/{pass_name}/*/*counter_collection.csv")[0]
+    f = max(glob.glob(f"{run}/{pass_name}/*/*counter_collection.csv"), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     by_disp = collections.OrderedDict()
     for r in rows:
@@ -62,6 +63,8 @@ for i, p in enumerate(plan):
         continue
     # a library call may be several kernels per launch: sum per launch
     per = max(1, len(sq) // 4)
+    # 4 timed launches per entry; a same-family warm-up launch of the NEXT entry may trail the group: drop it
+    sq, fe, wr, gr = sq[:4 * per], fe[:4 * per], wr[:4 * per], gr[:4 * per]
     n = len(sq) / per
     t = sum(e["t"] for e in gr) / n
     c = lambda grp, k: sum(e["c"].get(k, 0.0) for e in grp) / n  # noqa: E731

@@ -3,12 +3,13 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 run, tag = sys.argv[1], sys.argv[2]
 steps = 13
-stats = glob.glob(f"{run}/step/*/*_kernel_stats.csv")[0]
+stats = max(glob.glob(f"{run}/step/*/*_kernel_stats.csv"), key=os.path.getmtime)   # (a re-run merges next to older files)
 shutil.copy(stats, f"profiles/{tag}_step_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
