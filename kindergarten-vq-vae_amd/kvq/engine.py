@@ -438,9 +438,9 @@ class TrainEngine:
 
     # (N, K) -> workgroup tile of csrc/kvq_gemm2.hip for the shapes where it beats the tuned library at 8192 rows
     # (tools/gemm2_probe.py on MI355X, interleaved rounds; gpurun_out/g2_probe*.log); every other shape stays with hipBLASLt
-    _OWN_FWD = {(768, 768): "128x192", (768, 3072): "128x192"}                  # y = x . W^T + b        ("nt")
+    _OWN_FWD = {(768, 768): "128x192", (768, 3072): "128x192", (2304, 768): "128x192"}      # y = x . W^T + b        ("nt")
     _OWN_DGRAD = {(768, 768): "128x192", (768, 2304): "128x192", (768, 3072): "128x192", (3072, 768): "256x192",
-                  (768, 18432): "128x192"}                                      # gx = gy . W            ("nn")
+                  (768, 18432): "128x192", (768, 30528): "128x192"}                         # gx = gy . W            ("nn")
     # BertIntermediate / its backward with the activation inside the GEMM epilogue: (N, K) -> tile.  One v_exp_f32 + one v_rcp_f32
     # per element (Phi and phi share the exponential) and packed f32 FMAs; measured on MI355X (tools/gemm2_probe.py epi):
     # FFN1 forward 57.7 us against 44.5 + 19.3 (GEMM + gelu kernel), FFN2 backward 65.6 against 45.3 + 29.8; in the step

@@ -77,3 +77,6 @@ if SHAPES == "big":
         run("dgrad", "nn", T, 768, k, ["128x192", "128x256"], pool_bytes=2.5e9)
     for m in (18432, 30528):
         run("wgrad", "tn", m, 768, T, ["256x256", "256x192"], pool_bytes=2.5e9)
+if SHAPES == "bigfwd":
+    for n in (18432, 30528):
+        run("fwd", "nt", T, n, 768, ["256x256", "256x192"], pool_bytes=2.5e9)
