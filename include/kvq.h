@@ -234,7 +234,8 @@ int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mas
 
 /* bf16 attention flavour: 2 (default) = MFMA kernels (v_mfma_f32_32x32x16_bf16 for all five products), 1 = packed-dot
  * kernels (v_dot2c_f32_bf16); both round probabilities / dS to bf16 before P.V, dS.K, dS^T.Q, P^T.dO.  0 = convert-and-fma
- * kernels (f32 probabilities).  All flavours draw the same dropout mask.  f32 io always uses the f32 kernels. */
+ * kernels (f32 probabilities).  All flavours draw the same dropout mask.  f32 io always uses the f32 kernels.  The selection is
+ * per calling thread (a test / checker facility: the product path never changes it). */
 int kvq_attn_set_variant(int variant);
 
 /* ---- bf16 MFMA GEMM family, all three operand layouts of one nn.Linear's forward / backward (csrc/kvq_gemm2.hip) ----------
@@ -318,7 +319,7 @@ int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void
  *                          and leaves `step` (the dropout seed offset) alone, commit does step += 1.  For an optimiser whose
  *                          updates start while backward -- which still recomputes this step's dropout masks -- is running.
  * kvq_adam_step_dev        kvq_adam_step reading lr / bias corrections from the step state instead of taking them by value.
- * kvq_set_seed_offset      library-wide: every dropout-bearing kernel launched afterwards (kvq_dropout,
+ * kvq_set_seed_offset      per calling thread: every dropout-bearing kernel that thread launches afterwards (kvq_dropout,
  *                          kvq_dropout_residual_ln_*, kvq_attn_*) uses seed + step_state->step, read on the device at run
  *                          time; NULL switches it off.  A step captured once in a hipGraph then replays with fresh masks,
  *                          the right learning rate and bias corrections, with nothing patched from the host.

@@ -26,6 +26,8 @@
 //     launch of ~250 tiles of 128 x 256 -- one tile per CU over the whole 8192-token contraction, no split-K, no partial slabs.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "kvq_common.h"
 
 namespace kvq {
@@ -672,7 +674,7 @@ template <bool AK, bool BKM> using Cfg256x256 = Cfg<256, 256, 2, 4, AK, BKM, 2>;
 
 template <class C, int EPI = EPI_NONE>
 static int launch_cfg(const Params& P, hipStream_t st) {
-    static bool attr_done = false;                 // per instantiation; idempotent, so a race only repeats the call
+    static std::atomic<bool> attr_done{false};      // per instantiation; idempotent, so a race only repeats the call
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<C, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm2): %s", hipGetErrorString(e));
@@ -788,7 +790,7 @@ int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const 
     if (int rc = build_params(&q, 1, KVQ_GEMM_NT, KVQ_GEMM_TILE_128x256, P, "kvq_gemm_fp8_nt")) return rc;
     for (int i = 0; i < g2::MAX_PROBLEMS; ++i) { P.p[i].scaleA = scale_a; P.p[i].scaleB = scale_b; }
     typedef g2::Cfg128x256<true, true> Cf;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g2::gemm2_f8_kernel<Cf>), hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
         if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm2_f8): %s", hipGetErrorString(e));

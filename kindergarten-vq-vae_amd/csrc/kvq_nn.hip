@@ -1730,7 +1730,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
 
 using namespace kvq;
 
-static const unsigned long long* g_seed_off = nullptr;   // kvq_set_seed_offset
+static thread_local const unsigned long long* g_seed_off = nullptr;   // kvq_set_seed_offset: per calling thread (two engines on two threads do not see each other's)
 
 #define DISPATCH_DT(dt, CALL_F32, CALL_BF16) \
     do {                                     \
@@ -2084,7 +2084,7 @@ int kvq_dropout(const void* x, int64_t n, float p_drop, uint64_t seed, uint32_t 
     return check_launch("dropout_kernel");
 }
 
-static int g_attn_variant = 2;   // bf16 io: 2 = MFMA kernels, 1 = packed-dot kernels (v_dot2c_f32_bf16), 0 = convert-and-fma kernels
+static thread_local int g_attn_variant = 2;   // per calling thread; bf16 io: 2 = MFMA kernels, 1 = packed-dot kernels (v_dot2c_f32_bf16), 0 = convert-and-fma kernels
 
 int kvq_attn_set_variant(int variant) {
     KVQ_REQUIRE(variant >= 0 && variant <= 2, "kvq_attn_set_variant: variant %d unknown (0 fma, 1 dot2, 2 mfma)", variant);
