@@ -81,6 +81,7 @@ def main():
     from models.shelgon3.VectorQuantizer import VectorQuantizer
 
     rank, local, world = ddp.init_distributed()
+    grouped = world > 1 or dist.is_initialized()          # (a one-rank group: KVQ_DP_SINGLE_RANK=1, rehearsal of the RCCL branch)
     if world != a.gpus:
         raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a number for a different job size")
     if not torch.cuda.is_available():
@@ -144,20 +145,20 @@ def main():
     lib.kvq_prof_enable(a.steps + 4)
     if engine is not None:
         engine.reset_comm_timing()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = one_step(a.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     final_loss = float(loss)
     rccl_ranks, exposed_ms = 1, 0.0
-    if world > 1:
+    if grouped:
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)                                  # the ranks that actually take part in a collective
         rccl_ranks = int(probe.item())
@@ -171,7 +172,7 @@ def main():
     vq_avg_ms = sum(vq_ms) / max(len(vq_ms), 1) if vq_ms else float("nan")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -209,7 +210,7 @@ def main():
                        "global_batch": world * a.batch, "seq_len": a.seq_len, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
             "graph": bool(engine is not None and engine._graphs),      # False = the step ran as ~800 eager launches (capture failed or off)
-            "rccl_ranks": rccl_ranks, "dist_backend": (dist.get_backend() if world > 1 else None),
+            "rccl_ranks": rccl_ranks, "dist_backend": (dist.get_backend() if grouped else None),
             "exposed_comm_ms_per_step": exposed_ms,
             "roofline": {
                 "kernel": "vq_dist_packed_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
@@ -237,7 +238,7 @@ def main():
                                    "sample": f"{r['steps']} timed steps (median) of oracle/step_oracle.py at batch=8 seq_len={a.seq_len} "
                                              f"f32 (BASELINE.json configs[0]), {r['s_per_step']:.2f} s/step"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -30,7 +30,8 @@ def init_distributed(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # (KVQ_DP_SINGLE_RANK=1: a ONE-rank group, so that the RCCL branch of the engine can be rehearsed on a one-GPU box)
+    if (world > 1 or os.environ.get("KVQ_DP_SINGLE_RANK", "0") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

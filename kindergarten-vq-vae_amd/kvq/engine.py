@@ -287,6 +287,10 @@ class TrainEngine:
         self.use_graph = os.environ.get("KVQ_GRAPH", "1") != "0"
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # the gradient exchange runs when there is more than one rank -- or, for a rehearsal of the RCCL branch on a one-GPU box,
+        # with a ONE-rank process group and KVQ_DP_SINGLE_RANK=1 (every all-reduce, stream hand-over and graph interlude executes;
+        # the averages are over one rank)
+        self._dp = self.world > 1 or (dist.is_initialized() and os.environ.get("KVQ_DP_SINGLE_RANK", "0") == "1")
 
         # ---- flat parameter layout, in FORWARD order (gradients then complete from the tail backwards)
         entries, seen = [], set()
@@ -402,12 +406,12 @@ class TrainEngine:
         _ENGINES[model] = self
         self._param_versions = self._versions()
         # gradient all-reduce chunks (tail first)
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
-        self._avg_in_comm = self.world > 1 and dist.get_backend(process_group) == "nccl"   # RCCL averages itself; gloo sums
+        self.comm_stream = torch.cuda.Stream(device=dev) if self._dp else None
+        self._avg_in_comm = self._dp and dist.get_backend(process_group) == "nccl"   # RCCL averages itself; gloo sums
         self.chunk = max(bucket_mib * (1 << 20) // self.flat.grad.element_size(), 1 << 16)     # elements per all-reduce chunk
         self._pending_hi = self._wg_done_lo = self.flat.n
         self._works, self._works_late = [], []
-        self._ev_early = torch.cuda.Event() if self.world > 1 else None
+        self._ev_early = torch.cuda.Event() if self._dp else None
         self._time_comm = False
         self._comm_ev = []                       # (start, end) event pairs around the points where the compute stream waits for RCCL
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
@@ -848,18 +852,22 @@ class TrainEngine:
             lo = self._wg_done_lo                          # weight gradients of this layer still queued: final only above there
         else:
             self._wg_done_lo = lo
-        if self.world == 1:
+        if not self._dp:
             if self._fuse_opt and lo < self._adam_hi:
                 self._adam_early(lo, self._adam_hi)
                 self._adam_hi = lo
             return
         self._join_wgrads()
+        ranges = []
         while self._pending_hi - self.chunk >= lo:
-            self._reduce(self._pending_hi - self.chunk, self._pending_hi)
+            ranges.append((self._pending_hi - self.chunk, self._pending_hi))
             self._pending_hi -= self.chunk
         if partial and self._pending_hi > lo:
-            self._reduce(lo, self._pending_hi)
+            ranges.append((lo, self._pending_hi))
             self._pending_hi = lo
+        if ranges:                               # ONE eager interlude for all chunks that became final here (no empty graphs between)
+            grad = self.flat.grad
+            self._eager(lambda: [self._all_reduce_avg(grad[a:b]) for a, b in ranges])
 
     def _all_reduce_avg(self, t, late=False):
         works = self._works_late if late else self._works
@@ -877,10 +885,6 @@ class TrainEngine:
             self._cap.interlude(fn)
         else:
             fn()
-
-    def _reduce(self, a, b):
-        t = self.flat.grad[a:b]
-        self._eager(lambda: self._all_reduce_avg(t))
 
     def _settle(self, works):
         """On the side stream: wait for these collectives (and finish the average where the backend only sums)."""
@@ -939,7 +943,7 @@ class TrainEngine:
         """Forward (+ backward when compute_grads).  Returns dict(loss_recon, loss_vq, perplexity, acc, recon_ids, indices
         [, logits]).  dec_ids / dec_mask: the decoder's own input (Bagon.forward takes one; default = the encoder's).
         fuse_optimizer (train_step only; optimizer_step() MUST follow): parameters are updated while backward still runs."""
-        self._fuse_opt = bool(fuse_optimizer) and compute_grads and self._early_adam and self.world == 1
+        self._fuse_opt = bool(fuse_optimizer) and compute_grads and self._early_adam and not self._dp
         self._adam_hi, self._adam_forked = self.flat.n, False
         S = max(input_ids.shape[1], dec_ids.shape[1] if dec_ids is not None else 0)
         if S > 32:
@@ -1281,7 +1285,7 @@ class TrainEngine:
             self._after_update()
             return
         cut = 0
-        if self.world > 1:
+        if self._dp:
             cut = self._pending_hi                    # [0, cut) has not been sent yet (embedding gradients)
             self._eager(lambda: self._exchange_head(cut))
             self._pending_hi = fl.n
@@ -1292,7 +1296,7 @@ class TrainEngine:
         # step += 1, lr after the milestones, bias corrections: computed on the device, read there by the Adam kernels
         nnops.step_state_advance(self._state, self.lr, self.gamma, self.milestones, b1, b2)
         self._adam_ranges(cut, fl.n)                  # multi-GPU: runs while the head of the buffer is still being reduced
-        if self.world > 1:
+        if self._dp:
             self._eager(self._exchange_tail)
             self._adam_ranges(0, cut)
         self._adam_aux()
@@ -1375,7 +1379,7 @@ class TrainEngine:
             torch.cuda.synchronize(self.dev)
         except Exception:
             pass
-        if self.world > 1:
+        if self._dp:
             try:
                 self._settle(self._works)
                 self._exchange_tail()

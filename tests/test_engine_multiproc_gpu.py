@@ -104,3 +104,54 @@ def test_two_ranks_equal_single_process_big_batch(tmp_path):
         eng.train_step(ids, mask)
     bad = _differences(got["eager2"], model.state_dict(), 2)
     assert not bad, ("two ranks vs one process", bad[:5])
+
+
+def _worker_rccl_one_rank(rank, port, out):
+    """ONE rank, backend nccl (= RCCL): every all-reduce, side-stream hand-over and graph interlude of the data-parallel engine
+    executes on the GPU box's real collective library; with one rank the averages leave the gradients as they are."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      KVQ_DP_SINGLE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    import torch.distributed as dist
+    from kvq import ddp
+    from kvq.engine import TrainEngine
+    torch.cuda.set_device(0)
+    ddp.init_distributed("nccl")
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    ids, mask = _data()
+    saved = {}
+    for tag, use_graph in (("eager", False), ("graph", True)):
+        model = _build()
+        eng = TrainEngine(model, lr=1e-3, bucket_mib=0)
+        eng.use_graph = use_graph
+        assert eng._dp and eng.world == 1 and eng._avg_in_comm
+        eng.reset_comm_timing()
+        for _ in range(STEPS):
+            eng.train_step(ids, mask)
+        if use_graph:
+            assert len(eng._graphs) == 1 and len(next(iter(eng._graphs.values())).inter) >= 3
+        torch.cuda.synchronize()
+        saved[tag] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        saved[tag + "_exposed_ms"] = eng.exposed_comm_ms()
+    torch.save(saved, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_over_rccl_equals_the_plain_engine(tmp_path):
+    out = str(tmp_path / "rccl1.pt")
+    mp.spawn(_worker_rccl_one_rank, args=(_free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    from kvq.engine import TrainEngine
+    model = _build()
+    eng = TrainEngine(model, lr=1e-3)
+    eng.use_graph = False
+    assert not eng._dp
+    ids, mask = _data()
+    for _ in range(STEPS):
+        eng.train_step(ids, mask)
+    for tag in ("eager", "graph"):
+        bad = _differences(got[tag], model.state_dict(), STEPS)
+        assert not bad, (tag, bad[:5])
+        assert got[tag + "_exposed_ms"] >= 0.0
