@@ -674,6 +674,14 @@ class TrainEngine:
             return gx_accum
         return torch.mm(gy, W) if need_gx else None
 
+    def _dgrad(self, gy, W):
+        """gx = gy . W for a gradient that is not paired with a weight / bias gradient here (LM head, batched cross-K/V)."""
+        if self._own_fwd and self.dtype == torch.bfloat16 and gy.shape[0] >= 2048 and gy.stride(1) == 1 and W.stride(1) == 1:
+            tile = self._OWN_DGRAD.get((W.shape[1], W.shape[0]))
+            if tile is not None:
+                return nnops.gemm(gy, W, "nn", tile=tile)
+        return torch.mm(gy, W)
+
     # ------------------------------------------------------------------------------------------------------------
     # blocks: forward returns (output, saved); backward consumes saved
     # ------------------------------------------------------------------------------------------------------------
@@ -1069,7 +1077,7 @@ class TrainEngine:
                 self._defer_colsum(g_logits, fl.g("head.bias", rows=self.Vp))
         if tr["dec.emb.word"]:
             self._wgrad(g_logits, hN, fl.g("dec.emb.word", rows=self.Vp))            # [Vp,H] = g_logits^T hN
-        g_hN = torch.mm(g_logits, Wv)
+        g_hN = self._dgrad(g_logits, Wv)
         del logits, g_logits
         g_ta, _ = self._ln_bwd(g_hN, hpre, hmean, hrstd, fl.w32("head.ln.w"), 0.0, 0, 0,
                                g_gamma=fl.g("head.ln.w") if tr["head.ln.w"] else None,
@@ -1105,7 +1113,7 @@ class TrainEngine:
                 self._wgrad(g_kv_all, enc_out, fl.fused(self._cakv_w, fl.grad))
             if pb_kv_all is not None:
                 self._defer(pb_kv_all, fl.fused(self._cakv_b, fl.grad), B, pb_kv_all.shape[1], pb_kv_all.shape[1])
-            g_enc = torch.mm(g_kv_all, fl.fused(self._cakv_w, fl.shadow))
+            g_enc = self._dgrad(g_kv_all, fl.fused(self._cakv_w, fl.shadow))
             del g_kv_all, kv_all
             self._grads_done_down_to(self._cakv_w[0])
         self._emb_bwd("dec.emb.", g_y, demb_saved, tied_accumulate=True)
