@@ -141,3 +141,33 @@ def test_engine_graph_step_at_bert_base_shapes_trains():
     losses = [float(eng.train_step(ids, mask)["loss_recon"]) for _ in range(8)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
     assert eng._graphs, "the step was not captured"
+
+
+@pytest.mark.parametrize("mode", ["dec-head-ft", "enc-head-ft-dec-head-ft", "vq-ft"])
+def test_engine_frozen_modes_at_bert_base_shapes(mode, monkeypatch):
+    """The freeze modes of Bagon.set_mode (models/bagon/Bagon.py:87-179) at the benchmarked shapes: the weight-gradient queue
+    then holds irregular groups (frozen stacks contribute nothing, the two-layer flush policy sees partial pairs); own kernels
+    against the library routing on the same bf16 inputs, and no gradient for a frozen parameter."""
+    from kvq.engine import TrainEngine
+    ids, mask = _batch(seed=4)
+    runs = {}
+    for own in ("1", "0"):
+        monkeypatch.setenv("KVQ_OWN_GEMM", own)
+        model = _build(torch.bfloat16)
+        model.set_mode(mode)
+        eng = TrainEngine(model, lr=1e-4)
+        out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+        runs[own] = (out["loss_recon"].item(), out["loss_vq"].item(), _engine_grads(eng, model),
+                     {n for n, p in model.named_parameters() if p.requires_grad})
+        del eng, model
+        torch.cuda.empty_cache()
+    (l1, v1, g1, t1), (l0, v0, g0, t0) = runs["1"], runs["0"]
+    assert t1 == t0 and set(g1) == set(g0) and set(g1) <= t1
+    np.testing.assert_allclose(l1, l0, rtol=2e-3)
+    np.testing.assert_allclose(v1, v0, rtol=5e-3)
+    for n, g in g1.items():
+        if n.endswith("key.bias"):
+            continue
+        r = g0[n]
+        err = (g - r).norm().item() / max(r.norm().item(), 1e-30)
+        assert err < 3e-2, f"{mode}: {n}: own-GEMM vs library relative L2 difference {err:.3g}"
