@@ -141,6 +141,12 @@ int kvq_vq_ema_update(const void* z, const int64_t* idx, int64_t N, int K, int D
 int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, int64_t ld, int io_dtype,
                    float* row_loss, float* row_lse, int64_t* pred, float* loss, float* acc, void* stream);
 
+/* The same results from the per-tile statistics of kvq_gemm_bf16_ce (below): stats [N][tiles][4] f32 = (max, sum exp(x - max),
+ * first arg-max as int bits, unused) of row n over tile t's columns < V.  Reads ONE logit per row (the target's); the [N, V]
+ * logits are not read again.  SURVEY.md §8(f) rank 1. */
+int kvq_ce_forward_stats(const void* logits, const int64_t* target, int64_t N, int64_t ld, int io_dtype, const float* stats, int tiles,
+                         float* row_loss, float* row_lse, int64_t* pred, float* loss, float* acc, void* stream);
+
 /* g_logits[n,v] = g_loss/N * (softmax(logits_n)[v] - [v == target_n]); may alias logits (in place). */
 int kvq_ce_backward(const void* logits, const int64_t* target, const float* row_lse, const float* g_loss,
                     int64_t N, int V, int64_t ld, int io_dtype, void* g_logits, void* stream);
@@ -279,6 +285,14 @@ int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hou
 int64_t kvq_gemm_dgelu_partial_rows(int64_t M, int tile);
 int kvq_gemm_bf16_dgelu(const void* A, const void* B, const void* H, void* C, float* part, size_t part_bytes, int M, int N, int K,
                         int lda, int ldb, int ldc, int tile, void* stream);
+
+/* LM head with the forward half of the reconstruction loss in the GEMM epilogue (models/shelgon3/Trainer.py:94-101 after
+ * BertLMPredictionHead.decoder, modeling_bert.py:483-497):  C[M, ldc] (bf16) = A[M,K] . B[N,K]^T + bias  (layout NT, 256 x 256
+ * tiles) and stats [M][ceil(N/256)][4] f32 = per row and tile (max, sum exp(x - max), first arg-max, -) of the values as stored,
+ * over the columns < V (vocabulary padding excluded).  kvq_ce_forward_stats turns them into loss / lse / arg-max / accuracy. */
+size_t kvq_gemm_ce_stats_bytes(int M, int N);
+int kvq_gemm_bf16_ce(const void* A, const void* B, const void* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc, int V,
+                     float* stats, size_t stats_bytes, void* stream);
 
 /* ---- fp8 (OCP e4m3fn) forward GEMMs: extension named by BASELINE.json configs[4]; the reference is f32 throughout -> off by default.
  *   y = x . W^T + b of a BERT linear (modeling_bert.py:139-352) as  (sat(x sx) . sat(W sw)^T) / (sx sw) + b,  s = 448 / amax|.|

@@ -144,6 +144,34 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
     }
 }
 
+// The same row results from per-tile statistics left by the LM-head GEMM's epilogue (kvq_gemm_bf16_ce): stats [N][tiles][4] =
+// (max, sum of exp(x - max), first arg-max as int bits, -) of row n over the columns of tile t below V.  One thread per row merges
+// the tiles in column order (so the first maximum wins) and reads ONE logit, the target's: the [N, V] logits are not read again.
+template <int DT>
+__global__ __launch_bounds__(256) void ce_from_stats_kernel(const void* __restrict__ logits, const int64_t* __restrict__ target,
+                                                             int64_t N, int64_t ld, const float4* __restrict__ stats, int tiles,
+                                                             float* __restrict__ row_loss, float* __restrict__ row_lse,
+                                                             int64_t* __restrict__ pred) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float m = -INFINITY, s = 0.f;
+    int bi = INT_MAX;
+    const float4* row = stats + (size_t)n * tiles;
+    for (int t = 0; t < tiles; ++t) {
+        const float4 e = row[t];
+        const int ebi = __float_as_int(e.z);
+        const float nm = fmaxf(m, e.x);
+        const float sa = m > -INFINITY ? s * __expf(m - nm) : 0.f, sb = e.x > -INFINITY ? e.y * __expf(e.x - nm) : 0.f;
+        bi = (e.x > m || (e.x == m && ebi < bi)) ? ebi : bi;
+        m = nm; s = sa + sb;
+    }
+    const float lse = m + logf(s);
+    const float xt = IO<DT>::load1(logits, (size_t)n * ld + (size_t)target[n]);
+    row_lse[n] = lse;
+    row_loss[n] = lse - xt;
+    pred[n] = (int64_t)bi;
+}
+
 template <int DT>
 __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const void* logits, const int64_t* __restrict__ target,
                                                              const float* __restrict__ row_lse, const float* __restrict__ g_loss,
@@ -249,6 +277,28 @@ int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, 
     else
         hipLaunchKernelGGL(ce_fwd_kernel<KVQ_BF16>, dim3((unsigned)N), dim3(CE_THREADS), 0, st, logits, target, N, V, ld, row_loss, row_lse, pred);
     int rc = check_launch("ce_fwd_kernel");
+    if (rc) return rc;
+    if (loss || acc) {
+        hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, row_loss, pred, target, N, loss, acc);
+        rc = check_launch("ce_finalize_kernel");
+    }
+    return rc;
+}
+
+int kvq_ce_forward_stats(const void* logits, const int64_t* target, int64_t N, int64_t ld, int io_dtype, const float* stats, int tiles,
+                         float* row_loss, float* row_lse, int64_t* pred, float* loss, float* acc, void* stream) {
+    KVQ_REQUIRE(logits && target && stats && row_loss && row_lse && pred, "kvq_ce_forward_stats: null pointer argument");
+    KVQ_REQUIRE(N > 0 && N < (1ll << 31) && tiles > 0 && ld > 0, "kvq_ce_forward_stats: N=%lld tiles=%d ld=%lld out of range", (long long)N, tiles, (long long)ld);
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "kvq_ce_forward_stats: unsupported io dtype %d", io_dtype);
+    KVQ_REQUIRE(((uintptr_t)stats) % 16 == 0, "kvq_ce_forward_stats: 16-byte aligned statistics required");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((N + 255) / 256);
+    const float4* s4 = reinterpret_cast<const float4*>(stats);
+    if (io_dtype == KVQ_F32)
+        hipLaunchKernelGGL(ce_from_stats_kernel<KVQ_F32>, dim3(blocks), dim3(256), 0, st, logits, target, N, ld, s4, tiles, row_loss, row_lse, pred);
+    else
+        hipLaunchKernelGGL(ce_from_stats_kernel<KVQ_BF16>, dim3(blocks), dim3(256), 0, st, logits, target, N, ld, s4, tiles, row_loss, row_lse, pred);
+    int rc = check_launch("ce_from_stats_kernel");
     if (rc) return rc;
     if (loss || acc) {
         hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, st, row_loss, pred, target, N, loss, acc);

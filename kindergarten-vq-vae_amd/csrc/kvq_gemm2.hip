@@ -24,6 +24,7 @@
 //   * tiles are numbered so that each XCD (private L2) owns a contiguous band of tiles.
 //   * a launch can cover several problems of one layout ("grouped"): the weight gradients of one transformer layer are ONE
 //     launch of ~250 tiles of 128 x 256 -- one tile per CU over the whole 8192-token contraction, no split-K, no partial slabs.
+#include <limits.h>
 #include <stdlib.h>
 
 #include <atomic>
@@ -57,11 +58,13 @@ struct Problem {
     unsigned short* C2;                // EPI_GELU: second output gelu(C)
     const unsigned short* H;           // EPI_DGELU: pre-activation h [M, N] (row stride ldc); C = (A.B) * gelu'(h)
     float* part;                       // EPI_DGELU: [tiles_m][N] f32 column sums of C over each tile's rows (bias-gradient partials)
+                                       // EPI_CE: [M][tiles_n][4] softmax statistics of each row over each tile's columns < vlimit
+    int vlimit;                        // EPI_CE: columns >= vlimit (vocabulary padding) do not take part
     const float* scaleA;               // fp8 kernel: per-tensor quantisation scales of the two operands (device scalars)
     const float* scaleB;
 };
 
-constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2;
+constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_CE = 3;
 
 // GELU / GELU' of the fused epilogues, two elements at a time (v_pk_* on the f32 pairs a bf16 dword unpacks to).
 //   Phi(x) = 1/2 (1 + erf(x / sqrt2)),  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 output rounding):
@@ -370,6 +373,14 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
     }
     // lane holds, for (mi, ni): row m = wm*TM + mi*16 + (lane & 15), columns n = wn*TN + ni*16 + 4*(lane >> 4) + 0..3
     const int frow = lane & 15, fk = lane >> 4;
+    // EPI_CE: running softmax statistics of this lane's part of each of its FA rows, over the values AS STORED (bf16): maximum,
+    // sum of exp(x - maximum), first arg-max.  Columns are visited in increasing order, so an equal value never replaces an earlier one.
+    float cm[EPI == EPI_CE ? C::FA : 1], csum[EPI == EPI_CE ? C::FA : 1];
+    int cbi[EPI == EPI_CE ? C::FA : 1];
+    if constexpr (EPI == EPI_CE) {
+#pragma unroll
+        for (int mi = 0; mi < C::FA; ++mi) { cm[mi] = -INFINITY; csum[mi] = 0.f; cbi[mi] = INT_MAX; }
+    }
 #pragma unroll
     for (int ni = 0; ni < C::FB; ++ni) {
         const int nl = wn * C::TN + ni * 16 + 4 * fk;
@@ -381,9 +392,62 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
             const f32x4 v = acc[mi][ni] * mul + bv;
             const u16x4 o = {f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
             *reinterpret_cast<u16x4*>(smem + ml * C::CLD + nl * 2) = o;
+            if constexpr (EPI == EPI_CE) {
+                const int col = n0 + nl;
+                const float NEG = -INFINITY;
+                const float x0 = col + 0 < pr.vlimit ? bf16_to_f32(o.x) : NEG, x1 = col + 1 < pr.vlimit ? bf16_to_f32(o.y) : NEG;
+                const float x2 = col + 2 < pr.vlimit ? bf16_to_f32(o.z) : NEG, x3 = col + 3 < pr.vlimit ? bf16_to_f32(o.w) : NEG;
+                const float vm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+                if (vm > cm[mi]) {                                         // (strictly greater: the first maximum keeps the arg-max)
+                    csum[mi] *= __expf(cm[mi] - vm);                       // exp(-inf) = 0 the first time
+                    cm[mi] = vm;
+                    cbi[mi] = col + (x0 == vm ? 0 : x1 == vm ? 1 : x2 == vm ? 2 : 3);
+                }
+                if (cm[mi] > NEG) csum[mi] += (__expf(x0 - cm[mi]) + __expf(x1 - cm[mi])) + (__expf(x2 - cm[mi]) + __expf(x3 - cm[mi]));
+                // (a variant in base 2 with the padding test and the maximum update behind workgroup- / wave-uniform branches
+                //  measured SLOWER in the step: 18.78 against 18.55 ms)
+            }
+        }
+    }
+    if constexpr (EPI == EPI_CE) {
+        // the four lanes fk = 0..3 of a row hold interleaved 4-column groups: merge (the arg-max by value, then by lower index),
+        // then one entry per (row, wave column) into the scratch behind the bf16 tile; merged over the WN wave columns below
+        float4* cest = reinterpret_cast<float4*>(smem + C::BM * C::CLD);
+#pragma unroll
+        for (int mi = 0; mi < C::FA; ++mi) {
+            float m = cm[mi], sum = csum[mi];
+            int bi = cbi[mi];
+#pragma unroll
+            for (int mk = 16; mk <= 32; mk <<= 1) {
+                const float om = __shfl_xor(m, mk, 64), os = __shfl_xor(sum, mk, 64);
+                const int obi = __shfl_xor(bi, mk, 64);
+                const float nm = fmaxf(m, om);
+                const float sa = m > -INFINITY ? sum * __expf(m - nm) : 0.f, sb = om > -INFINITY ? os * __expf(om - nm) : 0.f;
+                bi = (om > m || (om == m && obi < bi)) ? obi : bi;
+                m = nm; sum = sa + sb;
+            }
+            if (fk == 0) cest[(wm * C::TM + mi * 16 + frow) * C::WN + wn] = make_float4(m, sum, __int_as_float(bi), 0.f);
         }
     }
     __syncthreads();
+    if constexpr (EPI == EPI_CE) {
+        const float4* cest = reinterpret_cast<const float4*>(smem + C::BM * C::CLD);
+        if (tid < C::BM && m0 + tid < pr.M) {
+            float m = -INFINITY, sum = 0.f;
+            int bi = INT_MAX;
+#pragma unroll
+            for (int q = 0; q < C::WN; ++q) {                              // wave columns in increasing column order
+                const float4 e = cest[tid * C::WN + q];
+                const int ebi = __float_as_int(e.z);
+                const float nm = fmaxf(m, e.x);
+                const float sa = m > -INFINITY ? sum * __expf(m - nm) : 0.f, sb = e.x > -INFINITY ? e.y * __expf(e.x - nm) : 0.f;
+                bi = (e.x > m || (e.x == m && ebi < bi)) ? ebi : bi;
+                m = nm; sum = sa + sb;
+            }
+            const int tn_ = n0 / C::BN;
+            reinterpret_cast<float4*>(pr.part)[(size_t)(m0 + tid) * pr.tiles_n + tn_] = make_float4(m, sum, __int_as_float(bi), 0.f);
+        }
+    }
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -737,7 +801,7 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
         d.band = d.tiles_n >= 8 ? 2 : 1;
         if (getenv("KVQ_GEMM_BAND")) d.band = atoi(getenv("KVQ_GEMM_BAND")) > 0 ? atoi(getenv("KVQ_GEMM_BAND")) : d.band;
         if (d.band > d.tiles_m) d.band = d.tiles_m;
-        d.C2 = nullptr; d.H = nullptr; d.part = nullptr; d.scaleA = nullptr; d.scaleB = nullptr;
+        d.C2 = nullptr; d.H = nullptr; d.part = nullptr; d.vlimit = 0; d.scaleA = nullptr; d.scaleB = nullptr;
         t0 += d.tiles_m * d.tiles_n;
     }
     for (int i = nprob; i < g2::MAX_PROBLEMS; ++i) P.p[i] = P.p[0];
@@ -778,6 +842,23 @@ int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hou
     hipStream_t st = (hipStream_t)stream;
     if (tile == KVQ_GEMM_TILE_256x192) return g2::launch_cfg<g2::Cfg256x192<true, true>, g2::EPI_GELU>(P, st);
     return g2::launch_cfg<g2::Cfg128x256<true, true>, g2::EPI_GELU>(P, st);
+}
+
+size_t kvq_gemm_ce_stats_bytes(int M, int N) { return (size_t)(M > 0 ? M : 0) * (size_t)((N + 255) / 256) * 16; }
+
+int kvq_gemm_bf16_ce(const void* A, const void* B, const void* bias, void* Cout, int M, int N, int K, int lda, int ldb, int ldc, int V,
+                     float* stats, size_t stats_bytes, void* stream) {
+    KVQ_REQUIRE(stats && V > 0 && V <= N, "kvq_gemm_bf16_ce: stats buffer and 0 < V <= N required");
+    KVQ_REQUIRE(stats_bytes >= kvq_gemm_ce_stats_bytes(M, N), "kvq_gemm_bf16_ce: stats buffer %zu < %zu bytes", stats_bytes, kvq_gemm_ce_stats_bytes(M, N));
+    KVQ_REQUIRE(((uintptr_t)stats) % 16 == 0, "kvq_gemm_bf16_ce: 16-byte aligned stats buffer required");
+    kvq_gemm_problem q;
+    q.A = A; q.B = B; q.C = Cout; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.accumulate = 0;
+    g2::Params P;
+    if (int rc = build_params(&q, 1, KVQ_GEMM_NT, KVQ_GEMM_TILE_256x256, P, "kvq_gemm_bf16_ce")) return rc;
+    for (int i = 0; i < g2::MAX_PROBLEMS; ++i) { P.p[i].part = stats; P.p[i].vlimit = V; }
+    static_assert(g2::Cfg256x256<true, true>::RPP * g2::Cfg256x256<true, true>::BN * 4 >= g2::Cfg256x256<true, true>::BM * g2::Cfg256x256<true, true>::WN * 16,
+                  "statistics scratch behind the epilogue tile");
+    return g2::launch_cfg<g2::Cfg256x256<true, true>, g2::EPI_CE>(P, (hipStream_t)stream);
 }
 
 int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const float* scale_b, const void* bias, void* C, int M, int N,

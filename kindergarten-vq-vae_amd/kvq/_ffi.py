@@ -91,6 +91,9 @@ SIGNATURES = {
     "kvq_gemm_bf16_dgelu": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_attn_set_variant": (_int, [_int]),
     "kvq_adam_step": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "kvq_ce_forward_stats": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kvq_gemm_ce_stats_bytes": (_sz, [_int, _int]),
+    "kvq_gemm_bf16_ce": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp, _sz, _vp]),
     "kvq_step_state_advance": (_int, [_vp, _f32, _f32, C.POINTER(_i64), _int, _f32, _f32, _vp]),
     "kvq_step_state_prepare": (_int, [_vp, _f32, _f32, C.POINTER(_i64), _int, _f32, _f32, _vp]),
     "kvq_step_state_commit": (_int, [_vp, _vp]),

@@ -271,6 +271,9 @@ class TrainEngine:
         self._wg_items, self._wg_keep = [], []
         self._wg_pair = os.environ.get("KVQ_WG_PAIR", "1") != "0"     # A/B switch: 0 = one grouped launch per layer (128 x 256 tiles)
         self._red_pair = os.environ.get("KVQ_RED_PAIR", "1") != "0"   # A/B switch: 0 = the batched reductions stay per layer
+        # LM head + the loss' forward statistics in one kernel (see _forward_backward): built and parity-tested in round 2, and
+        # 0.08 ms/step SLOWER than library GEMM + kvq_ce_forward (18.55 against 18.47 ms, gpurun_out/ab16.log): opt-in
+        self._own_lmce = os.environ.get("KVQ_OWN_LMCE", "0") == "1"
         # opt-in (KVQ_EARLY_ADAM=1): Adam for a layer's parameters as soon as their gradients are final, on a side stream beside the
         # rest of backward (one GPU only).  The update is pure HBM streaming and the GEMMs beside it live on L2 -> LDS bandwidth,
         # yet on MI355X the step got SLOWER: 18.88 against 18.18 ms (gpurun_out/ab6.log), and 19.5-19.8 against 18.86 with the
@@ -1039,15 +1042,25 @@ class TrainEngine:
         hN, hpre, hmean, hrstd = nnops.ln_fwd(ta, None, fl.w32("head.ln.w"), fl.w32("head.ln.b"), dcfg.layer_norm_eps)
         Wv = fl.w("dec.emb.word", rows=self.Vp)                              # [Vp,H], rows >= V are zero
         bv = fl.shadow[fl.seg["head.bias"][0]: fl.seg["head.bias"][0] + self.Vp]
-        logits = self._linear(hN, None, None, Wb=(Wv, bv), key="dec.emb.word")  # [N,Vp]
         tgt = d_ids.reshape(-1)
+        # LM head; with the own kernel its epilogue also leaves the loss' forward statistics per (row, 256-column tile): the
+        # [N, Vp] logits are then read by the loss only once more, in backward (opt-in, KVQ_OWN_LMCE=1; default: library GEMM + kvq_ce_forward)
+        lm_stats = None
+        if self._own_lmce and self._own_fwd and not self.fp8 and self.dtype == torch.bfloat16 and hN.shape[0] >= 2048 \
+                and hN.is_contiguous() and self.Vp % 8 == 0:
+            logits, lm_stats = nnops.gemm_ce(hN, Wv, bv, self.V)
+        else:
+            logits = self._linear(hN, None, None, Wb=(Wv, bv), key="dec.emb.word")  # [N,Vp]
         row_loss = torch.empty(Nd, dtype=torch.float32, device=self.dev)
         row_lse = torch.empty(Nd, dtype=torch.float32, device=self.dev)
         pred = torch.empty(Nd, dtype=torch.int64, device=self.dev)
         ce_out = torch.empty(2, dtype=torch.float32, device=self.dev)
-        check(lib().kvq_ce_forward(logits.data_ptr(), tgt.data_ptr(), Nd, self.V, self.Vp, self.io, row_loss.data_ptr(),
-                                   row_lse.data_ptr(), pred.data_ptr(), ce_out[0:].data_ptr(), ce_out[1:].data_ptr(), stream_ptr()),
-              "kvq_ce_forward")
+        if lm_stats is not None:
+            nnops.ce_forward_stats(logits, tgt, lm_stats, row_loss, row_lse, pred, ce_out[0:], ce_out[1:])
+        else:
+            check(lib().kvq_ce_forward(logits.data_ptr(), tgt.data_ptr(), Nd, self.V, self.Vp, self.io, row_loss.data_ptr(),
+                                       row_lse.data_ptr(), pred.data_ptr(), ce_out[0:].data_ptr(), ce_out[1:].data_ptr(), stream_ptr()),
+                  "kvq_ce_forward")
         out = dict(loss_recon=ce_out[0] * self.w_recon, loss_vq=(loss_vq * self.w_vq) if self.has_vq else None,
                    perplexity=perplexity, acc=ce_out[1], recon_ids=pred.view(B, Sd), indices=indices)
         if want_logits:

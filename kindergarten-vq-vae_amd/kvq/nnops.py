@@ -313,6 +313,26 @@ def gemm_dgelu(gy, w, h, tile="256x192"):
 
 
 # ---- fp8 forward GEMMs (csrc/kvq_fp8.hip, kvq_gemm_fp8_nt) -----------------------------------------------------------------------
+def gemm_ce(x, w, bias, V):
+    """(logits, stats): logits = x @ w.T + bias [M, N] and the per-(row, 256-column tile) softmax statistics of the columns < V
+    from the same kernel (LM head + forward half of the reconstruction loss; see ce_forward_stats)."""
+    M, K = x.shape
+    N = w.shape[0]
+    logits = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    stats = torch.empty((M, (N + 255) // 256, 4), dtype=torch.float32, device=x.device)
+    check(lib().kvq_gemm_bf16_ce(x.data_ptr(), w.data_ptr(), _p(bias), logits.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+                                 logits.stride(0), int(V), stats.data_ptr(), stats.numel() * 4, stream_ptr()), "kvq_gemm_bf16_ce")
+    return logits, stats
+
+
+def ce_forward_stats(logits, target, stats, row_loss, row_lse, pred, loss, acc):
+    """kvq_ce_forward's outputs from gemm_ce()'s statistics (reads one logit per row)."""
+    N = logits.shape[0]
+    check(lib().kvq_ce_forward_stats(logits.data_ptr(), target.data_ptr(), N, logits.stride(0), io_dtype_of(logits), stats.data_ptr(),
+                                     stats.shape[1], row_loss.data_ptr(), row_lse.data_ptr(), pred.data_ptr(), _p(loss), _p(acc),
+                                     stream_ptr()), "kvq_ce_forward_stats")
+
+
 def fp8_quantize(x, out=None):
     """bf16 [rows, cols] (unit column stride) -> (fp8 bytes [rows, cols] as uint8, scale [1] f32 on the device)."""
     require_gpu(x)

@@ -171,3 +171,28 @@ def test_engine_frozen_modes_at_bert_base_shapes(mode, monkeypatch):
         r = g0[n]
         err = (g - r).norm().item() / max(r.norm().item(), 1e-30)
         assert err < 3e-2, f"{mode}: {n}: own-GEMM vs library relative L2 difference {err:.3g}"
+
+
+def test_engine_lm_head_with_loss_statistics_option(monkeypatch):
+    """KVQ_OWN_LMCE=1 (the LM-head GEMM leaves the loss' forward statistics in its epilogue; kvq_ce_forward is not launched) against
+    the default schedule at the benchmarked vocabulary: same losses, same reconstruction ids, same gradients."""
+    from kvq.engine import TrainEngine
+    ids, mask = _batch(seed=6)
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("KVQ_OWN_LMCE", flag)
+        model = _build(torch.bfloat16)
+        eng = TrainEngine(model, lr=1e-4)
+        assert eng._own_lmce == (flag == "1")
+        out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+        runs[flag] = (out["loss_recon"].item(), out["acc"].item(), out["recon_ids"].clone(), _engine_grads(eng, model))
+        del eng, model
+        torch.cuda.empty_cache()
+    (l0, a0, r0, g0), (l1, a1, r1, g1) = runs["0"], runs["1"]
+    np.testing.assert_allclose(l1, l0, rtol=2e-3)       # the own 256 x 256 kernel against the library's summation order
+    assert (r1 != r0).float().mean().item() < 2e-3 and abs(a1 - a0) < 2e-3
+    for n, g in g1.items():
+        if n.endswith("key.bias"):
+            continue
+        err = (g - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-30)
+        assert err < 3e-2, f"{n}: relative L2 difference {err:.3g}"

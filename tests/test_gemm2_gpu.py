@@ -174,3 +174,33 @@ def test_multi_round_launches(layout, tile, shape):
     assert (big[M] == 3).all() and (big[:, :8] == 3).all() and (big[:, 8 + N:] == 3).all()
     out2 = nnops.gemm(a, b, layout, bias=bias, tile=tile)          # same launch again: bitwise reproducible
     assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("M,N,V,K", [(296, 776, 770, 128), (512, 256, 256, 64), (2048, 30528, 30522, 768)])
+def test_lm_head_gemm_with_loss_statistics(M, N, V, K):
+    """kvq_gemm_bf16_ce + kvq_ce_forward_stats against the plain GEMM + kvq_ce_forward: the logits bit
+    for bit, arg-max and accuracy exactly, lse / loss to f32 summation-order noise; padding columns >= V take no part."""
+    from kvq import nnops
+    from kvq._ffi import lib, check
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device="cuda") * 0.2).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda").to(torch.bfloat16)
+    b[V:] = 50.0                                                # a padding column that would win every arg-max if it were counted
+    tgt = torch.randint(0, V, (M,), generator=g, device="cuda")
+    ref_logits = nnops.gemm(x, w, "nt", bias=b, tile="256x256")
+    f = lambda: (torch.empty(M, device="cuda"), torch.empty(M, device="cuda"), torch.empty(M, dtype=torch.int64, device="cuda"),
+                 torch.empty(2, device="cuda"))
+    rl0, lse0, pred0, out0 = f()
+    check(lib().kvq_ce_forward(ref_logits.data_ptr(), tgt.data_ptr(), M, V, N, 1, rl0.data_ptr(), lse0.data_ptr(), pred0.data_ptr(),
+                               out0[0:].data_ptr(), out0[1:].data_ptr(), None), "kvq_ce_forward")
+    logits, stats = nnops.gemm_ce(x, w, b, V)
+    rl1, lse1, pred1, out1 = f()
+    nnops.ce_forward_stats(logits, tgt, stats, rl1, lse1, pred1, out1[0:], out1[1:])
+    assert torch.equal(logits, ref_logits)
+    assert torch.equal(pred1, pred0) and int(pred1.max()) < V
+    torch.testing.assert_close(lse1, lse0, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(rl1, rl0, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(out1, out0, rtol=1e-5, atol=1e-6)
+    want = torch.logsumexp(ref_logits[:, :V].float(), dim=1)
+    torch.testing.assert_close(lse1, want, rtol=2e-6, atol=2e-6)
