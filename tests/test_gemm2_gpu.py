@@ -176,7 +176,7 @@ def test_multi_round_launches(layout, tile, shape):
     assert torch.equal(out2, out)
 
 
-@pytest.mark.parametrize("M,N,V,K", [(296, 776, 770, 128), (512, 256, 256, 64), (2048, 30528, 30522, 768)])
+@pytest.mark.parametrize("M,N,V,K", [(296, 776, 770, 128), (512, 256, 256, 64), (2048, 30528, 30522, 768), (8192, 30528, 30522, 768)])
 def test_lm_head_gemm_with_loss_statistics(M, N, V, K):
     """kvq_gemm_bf16_ce + kvq_ce_forward_stats against the plain GEMM + kvq_ce_forward: the logits bit
     for bit, arg-max and accuracy exactly, lse / loss to f32 summation-order noise; padding columns >= V take no part."""
@@ -204,3 +204,9 @@ def test_lm_head_gemm_with_loss_statistics(M, N, V, K):
     torch.testing.assert_close(out1, out0, rtol=1e-5, atol=1e-6)
     want = torch.logsumexp(ref_logits[:, :V].float(), dim=1)
     torch.testing.assert_close(lse1, want, rtol=2e-6, atol=2e-6)
+    # the reference's own expression (models/shelgon3/Trainer.py:94-101): KL(one-hot || softmax), "batchmean", arg-max of the softmax
+    lg = ref_logits[:, :V].float()
+    kl = torch.nn.functional.kl_div(torch.log_softmax(lg, dim=-1), torch.nn.functional.one_hot(tgt, V).float(), reduction="batchmean")
+    torch.testing.assert_close(out1[0], kl, rtol=2e-5, atol=1e-6)
+    assert torch.equal(pred1, torch.softmax(lg, dim=-1).argmax(-1)) or (pred1 != lg.argmax(-1)).sum().item() == 0
+    torch.testing.assert_close(out1[1], (pred1 == tgt).float().mean(), rtol=0, atol=1e-6)
