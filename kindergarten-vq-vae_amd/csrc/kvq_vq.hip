@@ -137,7 +137,8 @@ template <> struct ZRaw<KVQ_BF16> {
 
 // (Round 2 also measured the token operand loaded straight into registers in B-fragment layout -- no LDS, no barrier, waves fully
 //  decoupled, same bits: 81 us against 65.5 us for this kernel at N = 8192, K = 512, D = 768.  The LDS stage is not what idles the
-//  matrix pipe.)
+//  matrix pipe.  Four token tiles per wave -- 128 tokens per workgroup, one workgroup per CU, every codebook fragment used for
+//  four MFMAs -- measured 70 us.)
 // TT = 32-token tiles per wave (1 or 2): with 2 the wave reuses each codebook fragment for two MFMAs (two independent
 // accumulator chains), halving the codebook traffic per flop; the workgroup then covers 64 tokens x 128 codes.
 // NST > 0: the stage count D/32 is a compile-time constant and the stage loop is fully unrolled (no loop back-edge,
