@@ -238,9 +238,24 @@ def main():
                                    "sample": f"{r['steps']} timed steps (median) of oracle/step_oracle.py at batch=8 seq_len={a.seq_len} "
                                              f"f32 (BASELINE.json configs[0]), {r['s_per_step']:.2f} s/step"}
         print(json.dumps(out), flush=True)
+        # a line whose number means something else than it says is worse than no line: fail the run
+        import math
+        if not math.isfinite(final_loss):
+            print(f"[bench] final loss is {final_loss}: the step diverged, the number above is not a training step", file=sys.stderr)
+            bad = 3
+        elif engine is not None and not out["graph"] and os.environ.get("KVQ_GRAPH", "1") != "0" and a.warmup + a.steps > 3:
+            print("[bench] the step was NOT replayed from hipGraphs (capture failed) although KVQ_GRAPH=0 was not asked for",
+                  file=sys.stderr)
+            bad = 4
+        else:
+            bad = 0
+    else:
+        bad = 0
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        raise SystemExit(bad)
 
 
 if __name__ == "__main__":

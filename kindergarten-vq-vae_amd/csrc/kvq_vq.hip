@@ -415,18 +415,18 @@ __global__ __launch_bounds__(FIN_THREADS) void vq_finalize_kernel(const double* 
                                                                    int64_t N, int K, int D, float beta,
                                                                    float* loss, float* perplexity, float* counts_f) {
     __shared__ double sd[FIN_THREADS];
-    __shared__ float sf[FIN_THREADS];
-    const int g = blockIdx.x, t = threadIdx.x;
+    __shared__ double sf[FIN_THREADS];        // the f32 entropy terms of the reference, summed in f64 (oracle/vq_oracle.c: a
+    const int g = blockIdx.x, t = threadIdx.x; // sequential f32 sum over K = 8192 terms drifts by 2e-4; torch.sum does not)
     const double* ts = tok_sumsq + (size_t)g * N;
     const unsigned* cu = counts_u + (size_t)g * K;
     double a = 0.0;
     for (int64_t n = t; n < N; n += FIN_THREADS) a += ts[n];
-    float ent = 0.f;
+    double ent = 0.0;
     for (int k = t; k < K; k += FIN_THREADS) {
         const float cnt = (float)cu[k];
         if (counts_f) counts_f[(size_t)g * K + k] = cnt;
         const float pk = cnt / (float)N;                 // e_mean                       (:84)
-        ent += pk * logf(pk + 1e-10f);
+        ent += (double)(pk * logf(pk + 1e-10f));
     }
     sd[t] = a;
     sf[t] = ent;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(FIN_THREADS) void vq_finalize_kernel(const double* 
         const float m = (float)(sd[0] / ((double)N * (double)D));
         const float bm = beta * m;
         loss[g] = m + bm;                                 // mean(.) + beta*mean(.)       (:76-77)
-        perplexity[g] = expf(-sf[0]);                     // (:85)
+        perplexity[g] = expf(-(float)sf[0]);              // (:85)
     }
 }
 

@@ -35,15 +35,15 @@ from .functional import _workspace
 
 V_ALIGN = 64   # vocabulary rows of the LM head are padded so logits rows are 128-byte aligned
 
-import weakref
-
-_ENGINES = weakref.WeakKeyDictionary()      # model -> the engine that owns its flat buffers (Bagon / Shelgon.forward reuse it)
+# model.__dict__["_kvq_engine"] = the engine that owns the model's flat buffers (Bagon / Shelgon.forward reuse it).  Model and
+# engine reference each other, so the pair is collected together -- a registry keyed by the model would keep both alive
+# (the engine holds the model strongly) together with ~4 GB of flat buffers at bert-base.
 _QUANTIZERS = ("VectorQuantizer", "MultiVectorQuantizer", "GumbelQuantizer")
 
 
 def engine_of(model, create=True):
     """The TrainEngine of `model` (its parameters live in that engine's flat buffers), created on first use."""
-    eng = _ENGINES.get(model)
+    eng = model.__dict__.get("_kvq_engine")
     if eng is not None and eng.flat.master.device != next(model.parameters()).device:
         eng = None                                         # the model was moved after the engine was built
     if eng is None and create:
@@ -406,7 +406,7 @@ class TrainEngine:
             if self.dtype != torch.bfloat16:
                 raise KvqError("TrainEngine: fp8 forward GEMMs need the bf16 compute dtype")
             self._fp8_setup()
-        _ENGINES[model] = self
+        model.__dict__["_kvq_engine"] = self
         self._param_versions = self._versions()
         # gradient all-reduce chunks (tail first)
         self.comm_stream = torch.cuda.Stream(device=dev) if self._dp else None
@@ -423,6 +423,12 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------------------------
     # small helpers
     # ------------------------------------------------------------------------------------------------------------
+    def __deepcopy__(self, memo):
+        return None                   # copy.deepcopy(model): the copy builds its own engine on first use (engine_of)
+
+    def __reduce__(self):
+        return (type(None), ())       # torch.save(model): the engine (streams, graphs, flat mirrors) is not part of a checkpoint
+
     @property
     def step_count(self):
         """Optimiser steps applied so far (host mirror of the device step state)."""
@@ -982,6 +988,8 @@ class TrainEngine:
         """Forward only, on the engine's kernels, with the [B, S, V] logits in the result: what Bagon.forward / Shelgon.forward
         return (models/bagon/Bagon.py:40-55, models/shelgon3/Shelgon.py:50-73)."""
         self.refresh_if_params_changed()
+        if getattr(self, "_epack", None) is not None:
+            self._E_version = None             # an evaluation forward never trusts a cached pack (a 3-us kernel; see _codebook_stamp)
         return self.forward_backward(enc_ids, enc_mask, training=training, compute_grads=False, dec_ids=dec_ids, dec_mask=dec_mask,
                                      want_logits=True, quantizer_training=quantizer_training)
 
@@ -1162,7 +1170,13 @@ class TrainEngine:
         if self._epack is not None:
             check(lib().kvq_vq_pack_codebook(self.E.data_ptr(), self.K, self.Dg, self.G, self._epack.data_ptr(), stream_ptr()),
                   "kvq_vq_pack_codebook")
-            self._E_version = self.E._version
+            self._E_version = self._codebook_stamp()
+
+    def _codebook_stamp(self):
+        """What tells a codebook write from outside: the tensor version (in-place torch ops, optimiser steps) and the module's
+        epoch counter (its EMA kernel writes through a raw pointer).  A `.data` write that bumps neither needs
+        sync_from_model(); forward_logits() repacks unconditionally."""
+        return (self.E._version, getattr(self.model.vector_quantizer, "codebook_epoch", 0))
 
     def _vq_fwd_call(self, z, N, D, G, z_q, idx, loss, perp, ws):
         if self._epack is None:
@@ -1170,7 +1184,7 @@ class TrainEngine:
                                        idx.data_ptr(), loss.data_ptr(), perp.data_ptr(), None, ws.data_ptr(), ws.numel(), stream_ptr()),
                   "kvq_vq_forward")
             return
-        if self.E._version != self._E_version:          # first call, or the codebook was written from outside the engine
+        if self._codebook_stamp() != self._E_version:   # first call, or the codebook was written from outside the engine
             self._repack_codebook()
         check(lib().kvq_vq_forward_packed(z.data_ptr(), self.E.data_ptr(), self._epack.data_ptr(), N, self.K, D, G, self.io,
                                           self.beta_vq, z_q.data_ptr(), idx.data_ptr(), loss.data_ptr(), perp.data_ptr(), None,
@@ -1355,6 +1369,8 @@ class TrainEngine:
         self.flat.refresh_shadow()
         if self.fp8:
             self._fp8_quantize_weights()
+        if getattr(self, "_epack", None) is not None:
+            self._E_version = None             # the codebook pack is rebuilt by the next quantiser call
 
     @staticmethod
     def supports(model, seq_len: int) -> bool:

@@ -83,3 +83,4 @@ class MultiVectorQuantizer(nn.Module):
 
     def ema_update(self, zg, idx):
         ema_codebook_update(zg, idx, self.ema_n, self.ema_m, self.codebooks().data, float(self.ema_decay), float(self.ema_eps))
+        self.codebook_epoch = getattr(self, "codebook_epoch", 0) + 1          # see VectorQuantizer.ema_update

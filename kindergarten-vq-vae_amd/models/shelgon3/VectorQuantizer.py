@@ -88,3 +88,6 @@ class VectorQuantizer(nn.Module):
     def ema_update(self, z2d, idx):
         """One EMA step of the codebook from the tokens z2d [N, e_dim] and their codes idx [N] (training steps only)."""
         ema_codebook_update(z2d, idx, self.ema_n, self.ema_m, self.embedding.weight.data, float(self.ema_decay), float(self.ema_eps))
+        # the kernel writes the codebook through a raw pointer (no tensor-version bump): tell whoever caches a derived copy
+        # (the TrainEngine's fragment-ordered pack) that it is stale
+        self.codebook_epoch = getattr(self, "codebook_epoch", 0) + 1

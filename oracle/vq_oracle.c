@@ -143,12 +143,14 @@ int kvq_oracle_vq_forward(const float* z, const float* E, int64_t N, int K, int 
     }
     float m = (float)(sumsq / ((double)N * (double)D));
     *loss = m + beta * m;                           /* mean(.) + beta*mean(.)         (:76-77) */
-    float ent = 0.0f;
+    /* The terms are the reference's f32 values; their SUM is kept in f64: torch.sum adds in a vectorised pairwise order whose
+       error stays near one ulp, a sequential f32 sum over K = 8192 terms drifts by 2e-4 (golden case k8192_default). */
+    double ent = 0.0;
     for (int k = 0; k < K; ++k) {
         float p = cnt[k] / (float)N;                /* e_mean                         (:84) */
-        ent += p * logf(p + 1e-10f);
+        ent += (double)(p * logf(p + 1e-10f));
     }
-    *perplexity = expf(-ent);                        /* (:85) */
+    *perplexity = expf(-(float)ent);                 /* (:85) */
     if (counts) memcpy(counts, cnt, (size_t)K * sizeof(float));
     free(cnt);
     return 0;

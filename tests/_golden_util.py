@@ -34,8 +34,13 @@ def make_inputs(seed, B, S, K, D, regime):
     return z, E, g, c
 
 
+# Cases too large for the per-case parametrised tests (each of those runs the single-threaded oracle several times): they have
+# tests of their own (tests/test_oracle_golden.py::test_c_oracle_large_codebook_near_ties, tests/test_vq_gpu.py::test_k8192_default_*).
+HEAVY = ("k8192_default",)
+
+
 def case_names():
-    return sorted(os.path.basename(p)[3:-4] for p in glob.glob(os.path.join(GOLDEN, "vq_*.npz")))
+    return sorted(n for n in (os.path.basename(p)[3:-4] for p in glob.glob(os.path.join(GOLDEN, "vq_*.npz"))) if n not in HEAVY)
 
 
 def load_case(name):
@@ -81,7 +86,9 @@ def check_indices(c, idx, max_ulps=8.0):
 # check_indices): the count measured when the fixtures were made (kvq order v1, oracle == HIP kernel bit for bit) plus slack.
 # Every committed case measures 0 -- including c2_default (N = 8192, 402 tokens with a top-2 gap below 1e-3, where the
 # reference itself differs from the fp64 arg-min on 9 tokens): a regression to a handful of flips must fail, not pass.
-MAX_NEAR_TIE_FLIPS = {"tiny_default": 0, "demo_default": 0, "c1_default": 0, "c2_default": 2}
+# k8192_default (BASELINE configs[3] in the near-tie regime: N = 8192, K = 8192, 5310 tokens with a top-2 gap below 1e-3, 93 below
+# 1e-5; the reference itself differs from the fp64 arg-min on 124 tokens) also measures 0 against the reference.
+MAX_NEAR_TIE_FLIPS = {"tiny_default": 0, "demo_default": 0, "c1_default": 0, "c2_default": 2, "k8192_default": 4}
 
 
 def check_flip_budget(c, ndiff):

@@ -155,3 +155,150 @@ def test_one_rank_over_rccl_equals_the_plain_engine(tmp_path):
         bad = _differences(got[tag], model.state_dict(), STEPS)
         assert not bad, (tag, bad[:5])
         assert got[tag + "_exposed_ms"] >= 0.0
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# The branch BASELINE.json configs[2] runs: bf16, bert-base widths, >= 2048 tokens per rank.  Only there do the grouped own
+# weight gradients exist, is their queue HELD across two layers (_flush_wgrads(force=False) -> False), does _wg_done_lo decide
+# which gradient chunk is final, do the single-launch LM-head / cross-K/V weight gradients and the batched cross-K/V run.
+# Two gloo ranks share the GPU; oracle = ONE process on the concatenated batch, dropout off.
+# The gradient buffers are filled with NaN before every step: a chunk that goes out before its gradients are written, or an
+# element nobody writes, cannot look right -- and with two DIFFERENT half batches a chunk that is reduced too early and then
+# overwritten by the late GEMM holds the local, not the averaged, gradient.
+# ----------------------------------------------------------------------------------------------------------------------------
+BASE_STEPS = 4                         # steps 1-2 eager, step 3 captures + replays, step 4 replays
+BASE_CHECK = (1, 4)
+BASE_LR = 1e-5
+
+
+def _build_base():
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    from models.shelgon3.Shelgon import Shelgon
+    from models.shelgon3.VectorQuantizer import VectorQuantizer
+    torch.manual_seed(0)
+    vq = VectorQuantizer(512, 768, 0.25, vq_codebook_init_values=torch.randn(512, 768))
+    vq.materialize_min_encodings = False
+    model = Shelgon("kvq-bert-base-2l", vq, "kvq-bert-base-2l", None, compute_dtype=torch.bfloat16).cuda()
+    model.set_mode("full")
+    return model.eval()
+
+
+def _data_base():
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    from dsentences.synthetic import random_token_batch
+    ids, mask = random_token_batch(128, 32, torch.Generator().manual_seed(11))
+    return ids.cuda(), mask.cuda()
+
+
+def _poison(eng):
+    eng.flat.grad.fill_(float("nan"))
+    for a in eng.aux:
+        a["g"].fill_(float("nan"))
+
+
+def _grad_snapshot(eng):
+    """Every trainable parameter's gradient (the padding between segments is not a gradient)."""
+    torch.cuda.synchronize()
+    out = {n: eng.flat.g(n).detach().clone() for n, p in eng.param_of.items() if p.requires_grad}
+    out["codebook"] = eng.gE.detach().clone()
+    return out
+
+
+def _worker_base(rank, world, port, ref_path, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    import torch.distributed as dist
+    from kvq import ddp
+    from kvq.engine import TrainEngine
+    torch.cuda.set_device(0)
+    ddp.init_distributed("gloo")
+    ids, mask = _data_base()
+    half = slice(rank * 64, rank * 64 + 64)
+    ref = torch.load(ref_path, map_location="cuda")
+    report = {}
+    for tag, use_graph in (("eager", False), ("graph", True)):
+        model = _build_base()
+        ddp.broadcast_parameters(model)
+        eng = TrainEngine(model, lr=BASE_LR, bucket_mib=4)
+        eng.use_graph = use_graph
+        assert eng.world == 2 and eng._dp and eng._own_wgrad and eng._cakv_batched
+        held, sent = [0], [0]
+        flush, reduce_ = eng._flush_wgrads, eng._all_reduce_avg
+
+        def counted_flush(force=True, _f=flush, _h=held):
+            done = _f(force)
+            _h[0] += (not done)
+            return done
+
+        def counted_reduce(t, late=False, _r=reduce_, _s=sent):
+            _s[0] += 1
+            return _r(t, late=late)
+        eng._flush_wgrads, eng._all_reduce_avg = counted_flush, counted_reduce
+        for step in range(1, BASE_STEPS + 1):
+            _poison(eng)
+            n_sent = sent[0]
+            res = eng.train_step(ids[half], mask[half])
+            if step == 1:
+                report[tag + "_chunks_per_step"] = sent[0] - n_sent
+            if step in BASE_CHECK:
+                got = _grad_snapshot(eng)
+                for n, g in got.items():
+                    r = ref[f"step{step}"][n].float()
+                    g = g.float()
+                    finite = bool(torch.isfinite(g).all())
+                    err = ((g - r).norm() / r.norm().clamp_min(1e-30)).item() if finite else float("inf")
+                    report[(tag, step, n)] = err
+                report[(tag, step, "loss")] = float(res["loss_recon"])
+        report[tag + "_held"] = held[0]
+        if use_graph:
+            assert len(eng._graphs) == 1
+            report["interludes"] = len(next(iter(eng._graphs.values())).inter)
+        del eng, model
+        torch.cuda.empty_cache()
+    if rank == 0:
+        torch.save(report, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_bf16_bert_base_shapes_equal_single_process(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    from kvq.engine import TrainEngine
+    # oracle: one process, the concatenated batch (equal token counts per half: the mean of the rank means is the global mean)
+    model = _build_base()
+    eng = TrainEngine(model, lr=BASE_LR)
+    eng.use_graph = False
+    assert not eng._dp
+    ids, mask = _data_base()
+    ref, ref_loss = {}, {}
+    for step in range(1, BASE_STEPS + 1):
+        _poison(eng)
+        res = eng.train_step(ids, mask)
+        if step in BASE_CHECK:
+            ref[f"step{step}"] = {k: v.cpu() for k, v in _grad_snapshot(eng).items()}
+            ref_loss[step] = float(res["loss_recon"])
+            assert all(bool(torch.isfinite(v).all()) for v in ref[f"step{step}"].values())
+    ref_path = str(tmp_path / "ref.pt")
+    torch.save(ref, ref_path)
+    del eng, model, ref
+    torch.cuda.empty_cache()
+    out = str(tmp_path / "dp_base.pt")
+    mp.spawn(_worker_base, args=(2, _free_port(), ref_path, out), nprocs=2, join=True)
+    rep = torch.load(out)
+    # the code under test really ran: the weight-gradient queue was held across layers, and the buffer left in >= 6 chunks
+    assert rep["eager_held"] >= 2 * BASE_STEPS and rep["graph_held"] >= 2, rep["eager_held"]
+    assert rep["eager_chunks_per_step"] >= 6 and rep["interludes"] >= 4, (rep["eager_chunks_per_step"], rep["interludes"])
+    worst = {}
+    for key, err in rep.items():
+        if not isinstance(key, tuple) or key[2] == "loss":
+            continue
+        tag, step, name = key
+        if name.endswith("k.b"):        # key bias: rounding noise (softmax shift invariance)
+            continue
+        worst[(tag, step)] = max(worst.get((tag, step), (0.0, "")), (err, name))
+        # bf16 gradients: each rank rounds its gradient to bf16 (2^-9) before the average, the one-process run rounds once
+        assert err < 1.5e-2, f"{tag} step {step}: {name}: relative L2 difference {err:.3g} to the one-process gradient"
+    print("two ranks (bf16, bert-base widths) vs one process, worst relative L2 per run:", worst)
+    for tag in ("eager", "graph"):
+        for step in BASE_CHECK:
+            assert abs(rep[(tag, step, "loss")] - ref_loss[step]) < 0.5, (tag, step)     # rank 0 sees its half only: same scale

@@ -237,6 +237,32 @@ def test_large_codebook_c4(kvq):
     assert counts.sum().item() == N
 
 
+def test_k8192_default_indices_equal_the_reference(kvq):
+    """BASELINE.json configs[3] in the near-tie regime (golden case k8192_default: N = 8192, K = 8192, default-init codebook,
+    produced by the reference module): ALL 8192 indices of the HIP kernel against the reference's, flip budget asserted;
+    bit for bit against the oracle on every token (the oracle runs on all host threads: 51 GFLOP of scalar f32)."""
+    import os
+    c = load_case("k8192_default")
+    D = c["D"]
+    got = _run(kvq, c["z"], c["E"], float(c["beta"]), c["g"], c["c"])
+    ndiff = check_indices(c, got["idx"])
+    check_flip_budget(c, ndiff)
+    np.testing.assert_allclose(got["loss"], c["loss"], rtol=2e-6)
+    O.set_threads(min(os.cpu_count() or 1, 16))
+    try:
+        ora = O.vq_forward(c["z"], c["E"], float(c["beta"]))
+    finally:
+        O.set_threads(1)
+    assert np.array_equal(got["idx"], ora["idx"]), f"{(got['idx'] != ora['idx']).sum()} indices differ from the oracle"
+    assert np.array_equal(got["z_q"], ora["z_q"].reshape(-1, D)) and np.array_equal(got["counts"], ora["counts"])
+    np.testing.assert_allclose(got["perplexity"], ora["perplexity"], rtol=1e-6)
+    if ndiff == 0:
+        np.testing.assert_allclose(got["perplexity"], c["perplexity"], rtol=2e-5)
+        np.testing.assert_allclose(got["grad_z"][c["tok_rows"]], c["grad_z_rows"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(got["grad_E"][c["code_rows"]], c["grad_E_rows"], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose((got["grad_E"].astype(np.float64) ** 2).sum(), c["grad_E_sq"], rtol=1e-4)
+
+
 def test_module_surface_matches_reference(kvq):
     """nn.Module drop-in: ctor, parameter name, 5-tuple, shapes and dtypes (VectorQuantizer.py:19-29,:93)."""
     from models.shelgon3.VectorQuantizer import VectorQuantizer
