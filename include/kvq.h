@@ -262,6 +262,10 @@ int kvq_attn_set_variant(int variant);
 #define KVQ_GEMM_TILE_128x256 1   /* 8 waves */
 #define KVQ_GEMM_TILE_256x192 2   /* 8 waves */
 #define KVQ_GEMM_TILE_256x256 3   /* 8 waves */
+/* OR-ed into `tile` (layout NT, one problem, no accumulate, M and N at least one tile, K >= 192): the PERSISTENT form -- one
+ * workgroup per CU walks its tiles, the k-tiles of successive tiles form one uninterrupted LDS-DMA stream and the epilogue
+ * goes from the accumulator registers straight to memory; pays when a CU owns two or more tiles. */
+#define KVQ_GEMM_PERSISTENT 0x100
 typedef struct kvq_gemm_problem {
     const void* A;
     const void* B;
@@ -275,7 +279,8 @@ int kvq_gemm_bf16(const void* A, const void* B, const void* bias, void* C, int M
                   int layout, int tile, int accumulate, void* stream);
 int kvq_gemm_grouped_bf16(const kvq_gemm_problem* problems, int n_problems, int layout, int tile, void* stream);
 /* BertIntermediate in one kernel (modeling_bert.py:325-337), layout NT: Hout = A.B^T + bias (kept for backward) and
- * Aout = gelu(Hout as rounded to bf16) -- exact-erf GELU (erf to 1.2e-7).  tile: KVQ_GEMM_TILE_256x192 or _128x256. */
+ * Aout = gelu(Hout as rounded to bf16) -- exact-erf GELU (erf to 1.2e-7).  tile: KVQ_GEMM_TILE_256x192 or _128x256, optionally
+ * | KVQ_GEMM_PERSISTENT. */
 int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hout, void* Aout, int M, int N, int K, int lda, int ldb,
                        int ldc, int tile, void* stream);
 /* Its backward through the activation, layout NN: C = (A.B) * gelu'(H)  (A = gradient of BertOutput.dense's output, B = its

@@ -66,6 +66,29 @@ struct Problem {
 
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_CE = 3;
 
+// Diagnostic build only (-DKVQ_G2_DIAG, tools/build_diag.sh -> lib/libkvq_diag.so; the product library has none of this): one
+// wave per workgroup stamps s_memtime at the phase boundaries of its tile into a buffer nothing else reads (guide, "In-kernel stamps").
+#ifdef KVQ_G2_DIAG
+__device__ unsigned long long* g_diag = nullptr;
+__device__ __forceinline__ void g2_stamp(int slot, unsigned long long v, int row = -1) {
+    // wave-uniform condition (scalar branch), one lane stores
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0 && g_diag != nullptr) {
+        unsigned vb = row >= 0 ? row : blockIdx.x;   // through an opaque VGPR: keeps the compiler from moving the kernel's own scalar
+        asm volatile("" : "+v"(vb));       // blockIdx chain (tile origin -> DMA bases, "s" asm operands) to the vector unit
+        if ((threadIdx.x & 63) == 0) __builtin_nontemporal_store(v, g_diag + (size_t)vb * 16 + slot);
+    }
+}
+#define G2_STAMP(slot) g2_stamp((slot), __builtin_amdgcn_s_memtime())
+#define G2_STAMP_VAL(slot, v) g2_stamp((slot), (unsigned long long)(v))
+#define G2_STAMP_ROW(row, slot) g2_stamp((slot), __builtin_amdgcn_s_memtime(), (row))
+#define G2_STAMP_ROW_VAL(row, slot, v) g2_stamp((slot), (unsigned long long)(v), (row))
+#else
+#define G2_STAMP(slot) do { } while (0)
+#define G2_STAMP_VAL(slot, v) do { } while (0)
+#define G2_STAMP_ROW(row, slot) do { } while (0)
+#define G2_STAMP_ROW_VAL(row, slot, v) do { } while (0)
+#endif
+
 // GELU / GELU' of the fused epilogues, two elements at a time (v_pk_* on the f32 pairs a bf16 dword unpacks to).
 //   Phi(x) = 1/2 (1 + erf(x / sqrt2)),  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 output rounding):
 //   1 - erf(|y|) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-y^2),  t = 1 / (1 + p |y|)
@@ -175,6 +198,9 @@ struct Stager {
         stepB = C::BKM ? (unsigned long long)BK * 2 : (unsigned long long)BK * 2 * pr.ldb;
         lds0 = (unsigned)(size_t)(lptr_t)smem + (unsigned)w * 1024u;
     }
+
+    // persistent tile loop: point the stager at another tile of the same problem (the ring, and with it lds0, stays)
+    __device__ __forceinline__ void retarget(const Problem& pr, char* smem, int m0, int n0, int w, int lane) { init(pr, smem, m0, n0, w, lane); }
 
     // one piece of the next k-tile (the one the bases point at) into ring slot `slot`
     template <int Q>
@@ -320,14 +346,27 @@ __device__ __forceinline__ TileId locate_tile(const Params& P, int id) {
     // `band` A tile rows (resident in its 4 MiB L2) and each B tile is fetched once per band instead of once per tile row
     // (fabric traffic per shape: profiles/r02_gemm_pmc.md).  band = 1: column-fastest.
     const int lt = id - pr.tile0;
-    const int per_band = pr.band * pr.tiles_n;
-    const int bnd = lt / per_band, inb = lt - bnd * per_band;
-    const int r0 = bnd * pr.band;
-    const int rb = pr.tiles_m - r0 < pr.band ? pr.tiles_m - r0 : pr.band;
     TileId t;
     t.pi = pi;
-    t.tn = inb / rb;
-    t.tm = r0 + inb - t.tn * rb;
+    if (pr.band < 0) {
+        // column bands (wide outputs): -band tile COLUMNS per band, column-fastest inside a band, every tile row swept per band.
+        // The band's B tiles (-band x BN x K x 2 bytes: <= 3 MiB) stay in the XCD's L2 while the A row tiles stream past once
+        // per band; with row bands every XCD re-reads ALL of B once per band of rows (LM head: 16 x 47 MB from the fabric)
+        const int wc = -pr.band;
+        const int per_band = wc * pr.tiles_m;
+        const int bnd = lt / per_band, inb = lt - bnd * per_band;
+        const int c0 = bnd * wc;
+        const int cb = pr.tiles_n - c0 < wc ? pr.tiles_n - c0 : wc;
+        t.tm = inb / cb;
+        t.tn = c0 + inb - t.tm * cb;
+    } else {
+        const int per_band = pr.band * pr.tiles_n;
+        const int bnd = lt / per_band, inb = lt - bnd * per_band;
+        const int r0 = bnd * pr.band;
+        const int rb = pr.tiles_m - r0 < pr.band ? pr.tiles_m - r0 : pr.band;
+        t.tn = inb / rb;
+        t.tm = r0 + inb - t.tn * rb;
+    }
     t.m0 = t.tm * C::BM;
     t.n0 = t.tn * C::BN;
     return t;
@@ -430,6 +469,7 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
         }
     }
     __syncthreads();
+    G2_STAMP(6);
     if constexpr (EPI == EPI_CE) {
         const float4* cest = reinterpret_cast<const float4*>(smem + C::BM * C::CLD);
         if (tid < C::BM && m0 + tid < pr.M) {
@@ -517,6 +557,16 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
     }
 }
 
+// ---- epilogue without LDS (the persistent kernel's, epilogue_regs below): the accumulators go to memory from the registers they
+// are in.  A lane of the 16x16x32 accumulator holds 4 consecutive columns (8 bytes of bf16) of one row; stored like that a
+// wave-instruction writes 16 rows x 32 bytes and the memory system sees quarter lines (measured in round 2: LM head 599 vs
+// 370 us).  One v_permlane16_swap per dword exchanges, between the lane pairs (fk, fk ^ 1), the quads of two neighbouring
+// 16-column blocks: afterwards an even-fk lane holds 8 consecutive columns of block ni0 and its odd partner 8 consecutive
+// columns of block ni0 + 1 -- one 16-byte store per lane, 16 rows x 64 contiguous bytes per wave-instruction, the other half of
+// each 128-byte line by the wave's next instruction.  No LDS, no barrier; in the one-tile-per-workgroup kernel it ties with the
+// LDS-transposed epilogue on every shape (tools/gemm2_probe_direct.py at round 3: 768^2 14.2 vs 14.3 us, FFN1 44.4 vs 44.4, LM
+// head 362.8 vs 366.1) -- what it buys is that a persistent tile loop keeps its ring in flight across it.
+
 // ---- the k loop of one tile.  On entry the ring holds k-tiles 0 .. min(NS, nkt) - 1 of the tile (issued, not yet waited for)
 //      and `sg` points at k-tile NS; on exit every wave has read its last fragments (the ring is free).
 template <class C>
@@ -524,6 +574,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
     if (nkt >= C::NS) wait_vm<(C::NS - 1) * C::PPW>();
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
+    G2_STAMP(4);
 
     // ---- main loop: per k-tile
     //   MFMA(f0) || read f1 || 2nd half of the pending refill  |  f1 ready, tile kt+1 landed, barrier  |
@@ -564,6 +615,9 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
 template <class C, int EPI>
 __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    G2_STAMP(0);
+    G2_STAMP_VAL(1, __builtin_amdgcn_s_memrealtime());
+    G2_STAMP_VAL(2, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / C::WN, wn = w % C::WN;
@@ -586,8 +640,16 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
 #pragma unroll
     for (int s = 0; s < C::NS; ++s)
         if (s < nkt) sg.issue(s);
+    G2_STAMP(3);
     mainloop<C>(acc, sg, smem, nkt, wm, wn, lane);
+    G2_STAMP(5);
     epilogue<C, EPI>(pr, smem, acc, biasv, tid, lane, wm, wn, m0, n0, ti.tm, 1.0f);
+#ifdef KVQ_G2_DIAG
+    G2_STAMP(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G2_STAMP(8);
+    G2_STAMP_VAL(9, __builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // (A persistent form -- gridDim.x = CUs workgroups walking the tiles, the next tile's ring issued before this tile's epilogue, the
@@ -602,6 +664,231 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
 //  125 for 128 x 256) and 32-deep k-tiles for m-major operands -- five slots for 256 x 256, six for 128 x 256, one barrier per
 //  32 -- which left the two-layer launch at 219 us (221 before) and cost 128 x 256 11 %.  Neither the prefetch distance nor the
 //  bytes per k-tile sets that time; tools/gemm2_probe_wgrad.py is the probe.)
+
+// ---- persistent form: one workgroup per CU walks its tiles, the ring NEVER drains -------------------------------------------------
+// Stamps of the one-tile-per-workgroup kernel (tools/gemm2_stamps.py, profiles/r03_gemm_stamps.md): a 256 x 256 tile of the
+// LM head lives 24 us, of which the 12 k-tiles take 14-16; the rest is start-up (2.9 us until the ring is issued, 1 us until
+// its first tile has landed), the epilogue (1.6 us accumulators -> LDS, 2.1 us LDS -> stores, 0.9 us until they are done) and
+// 0.6 us until the CU's next workgroup starts -- 9 us per tile in which the CU's L2 -> LDS path, the thing that bounds the
+// k loop (~60 GB/s per CU), moves nothing.  Here the k-tiles of a workgroup's tiles form ONE stream: the refill issued while
+// the last k-tiles of tile t are multiplied already belongs to tile t + 1, and the epilogue goes from the registers to memory
+// (epilogue_regs: no LDS, no barrier), so the only gap in the stream is the epilogue's own issue time.
+//   * the DMA loads and the epilogue's stores share the wave's in-order vmcnt queue: every counted wait of the loop stays
+//     correct (a static count can only wait for MORE than it needs when stores sit between the loads), and the first refill
+//     issued behind the stores is not waited for until NS - 1 k-tiles later
+//   * tiles of one workgroup: b, b + G, b + 2G ... (G = gridDim.x, a multiple of 8): all on one XCD's residue, and at every
+//     step the 32 CUs of an XCD work on 32 consecutive tiles of that XCD's band (locate_tile)
+//   * no per-lane clamping anywhere: an edge tile's ORIGIN is pulled back inside the matrix (n0 = N - BN: it overlaps its
+//     neighbour and both write the same values to the shared columns), so the stager's per-lane offsets are the same for every
+//     tile and a tile switch is two scalar base addresses; nothing the epilogue needs (bias) is held in registers across the
+//     k loop: the bias segment of a tile is one more DMA piece (wave 0) into a two-deep LDS buffer behind the ring
+template <class C>
+__device__ __forceinline__ void tile_origin(const Params& P, int id, int& m0, int& n0) {
+    const Problem& pr = P.p[0];
+    const int nt = P.ntiles, q = nt >> 3, r = nt & 7, x = id & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);                 // XCD-aware numbering (see locate_tile)
+    int tm, tn;
+    if (pr.band < 0) {
+        const int wc = -pr.band;
+        const int per_band = wc * pr.tiles_m;
+        const int bnd = id / per_band, inb = id - bnd * per_band;
+        const int c0 = bnd * wc;
+        const int cb = pr.tiles_n - c0 < wc ? pr.tiles_n - c0 : wc;
+        tm = inb / cb;
+        tn = c0 + inb - tm * cb;
+    } else {
+        const int per_band = pr.band * pr.tiles_n;
+        const int bnd = id / per_band, inb = id - bnd * per_band;
+        const int r0 = bnd * pr.band;
+        const int rb = pr.tiles_m - r0 < pr.band ? pr.tiles_m - r0 : pr.band;
+        tn = inb / rb;
+        tm = r0 + inb - tn * rb;
+    }
+    m0 = tm * C::BM < pr.M - C::BM ? tm * C::BM : pr.M - C::BM;
+    n0 = tn * C::BN < pr.N - C::BN ? tn * C::BN : pr.N - C::BN;
+}
+
+constexpr int BIAS_SLOT = 1024;                      // bytes of one bias buffer behind the ring (one DMA piece)
+
+// the bias segment [n0, n0 + BN) of a tile -> LDS bias buffer `par` (wave 0 only; lanes past the segment re-read its last chunk)
+template <class C>
+__device__ __forceinline__ void bias_dma(const Problem& pr, char* smem, int n0, int par, int lane) {
+    const int c = lane < C::BN / 8 ? lane : C::BN / 8 - 1;
+    const unsigned long long src = (unsigned long long)(pr.bias + n0 + c * 8);
+    const unsigned dst = (unsigned)(size_t)(lptr_t)smem + (unsigned)(C::NS * C::STAGE + par * BIAS_SLOT);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst)
+        : "memory");
+}
+
+// registers -> memory ("epilogue without LDS" above), bias from the LDS buffer, no masks (tile origins are inside the matrix)
+template <class C, int EPI>
+__device__ __forceinline__ void epilogue_regs(const Problem& pr, const char* biasl, f32x4 (&acc)[C::FA][C::FB], int lane, int wm, int wn,
+                                              int m0, int n0) {
+    static_assert(C::FB % 2 == 0, "column blocks are stored in pairs");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int frow = lane & 15, fk = lane >> 4;
+    const size_t coff = (size_t)(m0 + wm * C::TM + frow) * pr.ldc + n0 + wn * C::TN + (fk & 1) * 16 + 8 * (fk >> 1);
+    unsigned short* crow = pr.C + coff;
+    unsigned short* crow2 = EPI == EPI_GELU ? pr.C2 + coff : nullptr;
+#pragma unroll
+    for (int np = 0; np < C::FB / 2; ++np) {
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (biasl) {
+            const u16x4 t0 = *reinterpret_cast<const u16x4*>(biasl + (wn * C::TN + (2 * np) * 16 + 4 * fk) * 2);
+            const u16x4 t1 = *reinterpret_cast<const u16x4*>(biasl + (wn * C::TN + (2 * np + 1) * 16 + 4 * fk) * 2);
+            b0 = f32x4{bf16_to_f32(t0.x), bf16_to_f32(t0.y), bf16_to_f32(t0.z), bf16_to_f32(t0.w)};
+            b1 = f32x4{bf16_to_f32(t1.x), bf16_to_f32(t1.y), bf16_to_f32(t1.z), bf16_to_f32(t1.w)};
+        }
+#pragma unroll
+        for (int mi = 0; mi < C::FA; ++mi) {
+            const f32x4 v0 = acc[mi][2 * np] + b0, v1 = acc[mi][2 * np + 1] + b1;
+            unsigned x0 = (unsigned)f32_to_bf16(v0.x) | ((unsigned)f32_to_bf16(v0.y) << 16), x1 = (unsigned)f32_to_bf16(v0.z) | ((unsigned)f32_to_bf16(v0.w) << 16);
+            unsigned y0 = (unsigned)f32_to_bf16(v1.x) | ((unsigned)f32_to_bf16(v1.y) << 16), y1 = (unsigned)f32_to_bf16(v1.z) | ((unsigned)f32_to_bf16(v1.w) << 16);
+            const size_t eoff = (size_t)(mi * 16) * pr.ldc + np * 32;
+            {
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                const u32x4 vv = {s0.x, s1.x, s0.y, s1.y};
+                __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(crow + eoff));
+            }
+            if constexpr (EPI == EPI_GELU) {                               // second output: gelu of the values as stored (bf16)
+                const f32x2 g0 = gelu2(unpack_bf16x2(x0)), g1 = gelu2(unpack_bf16x2(x1));
+                const f32x2 g2 = gelu2(unpack_bf16x2(y0)), g3 = gelu2(unpack_bf16x2(y1));
+                x0 = (unsigned)f32_to_bf16(g0.x) | ((unsigned)f32_to_bf16(g0.y) << 16); x1 = (unsigned)f32_to_bf16(g1.x) | ((unsigned)f32_to_bf16(g1.y) << 16);
+                y0 = (unsigned)f32_to_bf16(g2.x) | ((unsigned)f32_to_bf16(g2.y) << 16); y1 = (unsigned)f32_to_bf16(g3.x) | ((unsigned)f32_to_bf16(g3.y) << 16);
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                const u32x4 vv = {s0.x, s1.x, s0.y, s1.y};
+                __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(crow2 + eoff));
+            }
+        }
+    }
+}
+
+template <class C, int EPI>
+__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm3_kernel(Params P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w / C::WN, wn = w % C::WN;
+    const Problem& pr = P.p[0];
+    const int nkt = pr.K / BK;                       // >= NS (host check)
+    const int G = gridDim.x, ntiles = P.ntiles;
+    int tc = blockIdx.x;                             // the tile being multiplied
+    int ts = tc, sk = 0, spar = 0;                   // the stager's cursor: tile, k-tile to issue next, parity of its tile count
+    const int total = ((ntiles - 1 - (int)blockIdx.x) / G + 1) * nkt;      // k-tiles of this workgroup's stream
+    int g = 0;                                       // k-tiles of the stream consumed so far
+    const bool has_bias = pr.bias != nullptr;
+
+    int m0, n0;
+    tile_origin<C>(P, tc, m0, n0);
+    Stager<C> sg;
+    {
+        Problem un = pr;                             // the per-lane offsets of an interior tile serve every tile (no clamping)
+        un.M = INT_MAX; un.N = INT_MAX;
+        sg.init(un, smem, 0, 0, w, lane);
+    }
+    auto aim = [&](int am0, int an0) {               // the two scalar bases of a tile's k-tile 0
+        sg.baseA = (unsigned long long)(C::AK ? pr.A + (size_t)am0 * pr.lda : pr.A + am0);
+        sg.baseB = (unsigned long long)(C::BKM ? pr.B + (size_t)an0 * pr.ldb : pr.B + an0);
+    };
+    aim(m0, n0);
+    if (has_bias && w == 0) bias_dma<C>(pr, smem, n0, 0, lane);
+    auto next_ktile = [&]() {                        // after a whole k-tile has been issued
+        sg.advance();
+        if (++sk == nkt) {
+            sk = 0;
+            ts += G;
+            spar ^= 1;
+            if (ts < ntiles) {
+                int sm0, sn0;
+                tile_origin<C>(P, ts, sm0, sn0);
+                aim(sm0, sn0);
+                if (has_bias && w == 0) bias_dma<C>(pr, smem, sn0, spar, lane);
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+        sg.template pieces<0, C::PPW>(s);
+        next_ktile();
+    }
+    f32x4 acc[C::FA][C::FB];
+#pragma unroll
+    for (int mi = 0; mi < C::FA; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::FB; ++ni) acc[mi][ni] = 0.f;
+
+    wait_vm<(C::NS - 1) * C::PPW>();
+    __builtin_amdgcn_s_barrier();
+    Frags<C> f0, f1;
+    read_frags<C>(f0, smem, wm, wn, 0, lane);
+    constexpr int PH = C::NS == 2 ? C::PPW : C::PPW / 2;
+    constexpr int NST = C::FA * (C::FB / 2) * (EPI == EPI_GELU ? 2 : 1);     // stores of one epilogue, per wave
+    int slot = 0, pslot = 0, cpar = 0;
+    bool pending = false;
+    for (;;) {
+        G2_STAMP_ROW(tc, 0);
+        G2_STAMP_ROW_VAL(tc, 1, __builtin_amdgcn_s_memrealtime());
+        G2_STAMP_ROW_VAL(tc, 2, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));
+        for (int kt = 0; kt < nkt; ++kt, ++g) {
+            if (kt == 1) G2_STAMP_ROW(tc, 3);
+            if (kt == 2) G2_STAMP_ROW(tc, 4);
+            const char* st = smem + slot * C::STAGE;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            mma<C, PH, C::PPW>(acc, f0, f1, st, 1, wm, wn, lane, sg, pslot, pending);
+            if (pending) next_ktile();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            pending = false;
+            const int nslot = slot + 1 == C::NS ? 0 : slot + 1;
+            if (g + 1 < total) {                                           // the stream goes on (in this tile or the next)
+                // first k-tile behind a tile boundary: the previous epilogue's NST stores are YOUNGER than every refill issued
+                // so far -- they may stay in flight, the loop must not wait for them here (extra operations in the queue, such as
+                // wave 0's bias piece, only make a counted wait more conservative: completion is in issue order)
+                if (g + C::NS > total) wait_vm<0>();
+                else if (kt == 0 && g > 0) wait_vm<(C::NS - 2) * C::PPW + NST>();
+                else wait_vm<(C::NS - 2) * C::PPW>();
+                __builtin_amdgcn_s_barrier();
+                pending = ts < ntiles;
+                pslot = slot;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma<C, 0, PH>(acc, f1, f0, smem + nslot * C::STAGE, 0, wm, wn, lane, sg, pslot, pending);
+            slot = nslot;
+        }
+        // ---- tile finished: the rest of the pending refill first (the stream must not wait for the stores), then the stores
+        if constexpr (PH < C::PPW) {
+            if (pending) {
+                sg.template pieces<PH, C::PPW>(pslot);
+                next_ktile();
+                pending = false;
+            }
+        }
+        G2_STAMP_ROW(tc, 5);
+        epilogue_regs<C, EPI>(pr, has_bias ? smem + C::NS * C::STAGE + cpar * BIAS_SLOT : nullptr, acc, lane, wm, wn, m0, n0);
+        G2_STAMP_ROW(tc, 7);
+        G2_STAMP_ROW_VAL(tc, 9, __builtin_amdgcn_s_memrealtime());
+        tc += G;
+        if (tc >= ntiles) break;
+        cpar ^= 1;
+        tile_origin<C>(P, tc, m0, n0);
+#pragma unroll
+        for (int mi = 0; mi < C::FA; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < C::FB; ++ni) acc[mi][ni] = 0.f;
+    }
+}
 
 // ---- fp8 (OCP e4m3) operands, NT layout: forward projections of BASELINE.json configs[4] --------------------------------------
 //   C[M,N] (bf16) = (A8[M,K] . B8[N,K]^T) / (sA * sB) + bias,   A8 = sat(x * sA), B8 = sat(W * sB)  (per-tensor scales, on device)
@@ -735,6 +1022,7 @@ template <bool AK, bool BKM> using Cfg128x256 = Cfg<128, 256, 2, 4, AK, BKM, 3>;
 template <bool AK, bool BKM> using Cfg256x192 = Cfg<256, 192, 4, 2, AK, BKM, 2>;     // 8 waves, 112 KiB
 template <bool AK, bool BKM> using Cfg128x192 = Cfg<128, 192, 2, 4, AK, BKM, 3>;     // 8 waves, 120 KiB: 256 tiles at N = 768
 template <bool AK, bool BKM> using Cfg256x256 = Cfg<256, 256, 2, 4, AK, BKM, 2>;     // 8 waves, 128 KiB
+template <bool AK, bool BKM> using Cfg128x192p = Cfg<128, 192, 4, 2, AK, BKM, 3>;    // persistent form: an even number of 16-column blocks per wave
 
 template <class C, int EPI = EPI_NONE>
 static int launch_cfg(const Params& P, hipStream_t st) {
@@ -746,6 +1034,34 @@ static int launch_cfg(const Params& P, hipStream_t st) {
     }
     hipLaunchKernelGGL((gemm2_kernel<C, EPI>), dim3((unsigned)P.ntiles), dim3(C::THREADS), C::LDS, st, P);
     return check_launch("gemm2_kernel");
+}
+
+static int persistent_grid() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n / 8 * 8 > 0 ? n / 8 * 8 : 8;        // a multiple of the 8 XCDs: a workgroup's tiles then stay on one XCD's residue
+    }
+    return cus;
+}
+
+template <class C, int EPI>
+static int launch_persistent(const Params& P, hipStream_t st) {
+    if (P.nprob != 1 || P.p[0].accumulate) return fail(KVQ_E_INVALID, "kvq_gemm (persistent): one problem, no accumulate");
+    if (P.p[0].K / BK < C::NS) return fail(KVQ_E_INVALID, "kvq_gemm (persistent): K=%d below %d k-tiles", P.p[0].K, C::NS);
+    if (P.p[0].M < C::BM || P.p[0].N < C::BN) return fail(KVQ_E_INVALID, "kvq_gemm (persistent): the matrix must hold one whole tile");
+    constexpr int LDSP = C::NS * C::STAGE + 2 * BIAS_SLOT;
+    static_assert(LDSP <= 160 * 1024, "LDS budget (persistent)");
+    static std::atomic<bool> attr_done{false};
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<C, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+        if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm3): %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int grid = P.ntiles < persistent_grid() ? P.ntiles : persistent_grid();
+    hipLaunchKernelGGL((gemm3_kernel<C, EPI>), dim3((unsigned)grid), dim3(C::THREADS), LDSP, st, P);
+    return check_launch("gemm3_kernel");
 }
 
 template <template <bool, bool> class T>
@@ -775,9 +1091,12 @@ using namespace kvq;
 static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, int tile, g2::Params& P, const char* who) {
     KVQ_REQUIRE(probs && nprob >= 1 && nprob <= g2::MAX_PROBLEMS, "%s: 1..%d problems per launch", who, g2::MAX_PROBLEMS);
     KVQ_REQUIRE(layout == KVQ_GEMM_NT || layout == KVQ_GEMM_NN || layout == KVQ_GEMM_TN, "%s: unknown layout %d", who, layout);
+    const bool persistent = (tile & KVQ_GEMM_PERSISTENT) != 0;
+    tile &= ~KVQ_GEMM_PERSISTENT;
     KVQ_REQUIRE(tile >= KVQ_GEMM_TILE_128x192 && tile <= KVQ_GEMM_TILE_256x256, "%s: unknown tile %d", who, tile);
     int bm, bn;
     g2::tile_of(tile, bm, bn);
+    (void)persistent;
     P.nprob = nprob;
     int t0 = 0;
     for (int i = 0; i < nprob; ++i) {
@@ -796,11 +1115,15 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
         d.M = q.M; d.N = q.N; d.K = q.K; d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc;
         d.tiles_m = (q.M + bm - 1) / bm; d.tiles_n = (q.N + bn - 1) / bn;
         d.tile0 = t0; d.accumulate = q.accumulate;
-        // wide outputs: bands of two tile rows (measured on MI355X, tools/gemm2_probe_big.py: LM head 256x256 387 -> 370 us, cross-K/V
-        // 238 -> 222 us; taller bands lose again -- the C rows written together get shorter); a few tile columns: column-fastest
-        d.band = d.tiles_n >= 8 ? 2 : 1;
-        if (getenv("KVQ_GEMM_BAND")) d.band = atoi(getenv("KVQ_GEMM_BAND")) > 0 ? atoi(getenv("KVQ_GEMM_BAND")) : d.band;
+        // Tile order.  A few tile columns: column-fastest.  Wide outputs (>= 8 tile columns): COLUMN bands of 6 tile columns, every
+        // tile row swept per band -- the band's B tiles (6 x 256 x 768 x 2 B = 2.4 MB) stay in the XCD's L2 and the A row tiles
+        // stream past once per band; with bands of two tile ROWS (round 2) every XCD pulled all of B through the fabric once per
+        // band.  tools/gemm2_probe_band.py on MI355X: LM head 362.6 -> 354.7 us (one tile per workgroup), 430 -> 362 (persistent);
+        // cross-K/V persistent 208 -> 203; 4, 8 or 9 columns and taller row bands are all slower.
+        d.band = d.tiles_n >= 8 ? -6 : 1;
+        if (getenv("KVQ_GEMM_BAND") && atoi(getenv("KVQ_GEMM_BAND")) != 0) d.band = atoi(getenv("KVQ_GEMM_BAND"));
         if (d.band > d.tiles_m) d.band = d.tiles_m;
+        if (-d.band > d.tiles_n) d.band = -d.tiles_n;
         d.C2 = nullptr; d.H = nullptr; d.part = nullptr; d.vlimit = 0; d.scaleA = nullptr; d.scaleB = nullptr;
         t0 += d.tiles_m * d.tiles_n;
     }
@@ -811,10 +1134,25 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
 
 extern "C" {
 
+#ifdef KVQ_G2_DIAG
+int kvq_diag_set_buffer(void* buf) {          // diagnostic library only: [tiles of the next launches][16] u64, or null
+    return hipMemcpyToSymbol(HIP_SYMBOL(g2::g_diag), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int kvq_gemm_grouped_bf16(const kvq_gemm_problem* probs, int nprob, int layout, int tile, void* stream) {
     g2::Params P;
     if (int rc = build_params(probs, nprob, layout, tile, P, "kvq_gemm_grouped_bf16")) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (tile & KVQ_GEMM_PERSISTENT) {
+        KVQ_REQUIRE(layout == KVQ_GEMM_NT, "kvq_gemm (persistent): layout NT only");
+        switch (tile & ~KVQ_GEMM_PERSISTENT) {
+            case KVQ_GEMM_TILE_128x256: return g2::launch_persistent<g2::Cfg128x256<true, true>, g2::EPI_NONE>(P, st);
+            case KVQ_GEMM_TILE_256x192: return g2::launch_persistent<g2::Cfg256x192<true, true>, g2::EPI_NONE>(P, st);
+            case KVQ_GEMM_TILE_256x256: return g2::launch_persistent<g2::Cfg256x256<true, true>, g2::EPI_NONE>(P, st);
+            default: return g2::launch_persistent<g2::Cfg128x192p<true, true>, g2::EPI_NONE>(P, st);
+        }
+    }
     switch (tile) {
         case KVQ_GEMM_TILE_128x256: return g2::launch_layout<g2::Cfg128x256>(layout, P, st);
         case KVQ_GEMM_TILE_256x192: return g2::launch_layout<g2::Cfg256x192>(layout, P, st);
@@ -833,13 +1171,18 @@ int kvq_gemm_bf16(const void* A, const void* B, const void* bias, void* C, int M
 int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hout, void* Aout, int M, int N, int K, int lda, int ldb,
                        int ldc, int tile, void* stream) {
     KVQ_REQUIRE(Aout && ((uintptr_t)Aout & 15) == 0, "kvq_gemm_bf16_gelu: null / misaligned second output");
-    KVQ_REQUIRE(tile == KVQ_GEMM_TILE_256x192 || tile == KVQ_GEMM_TILE_128x256, "kvq_gemm_bf16_gelu: tile must be 256x192 or 128x256");
+    const int base = tile & ~KVQ_GEMM_PERSISTENT;
+    KVQ_REQUIRE(base == KVQ_GEMM_TILE_256x192 || base == KVQ_GEMM_TILE_128x256, "kvq_gemm_bf16_gelu: tile must be 256x192 or 128x256");
     kvq_gemm_problem q;
     q.A = A; q.B = B; q.C = Hout; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.accumulate = 0;
     g2::Params P;
     if (int rc = build_params(&q, 1, KVQ_GEMM_NT, tile, P, "kvq_gemm_bf16_gelu")) return rc;
     for (int i = 0; i < g2::MAX_PROBLEMS; ++i) P.p[i].C2 = (unsigned short*)Aout;
     hipStream_t st = (hipStream_t)stream;
+    if (tile & KVQ_GEMM_PERSISTENT) {
+        if (base == KVQ_GEMM_TILE_256x192) return g2::launch_persistent<g2::Cfg256x192<true, true>, g2::EPI_GELU>(P, st);
+        return g2::launch_persistent<g2::Cfg128x256<true, true>, g2::EPI_GELU>(P, st);
+    }
     if (tile == KVQ_GEMM_TILE_256x192) return g2::launch_cfg<g2::Cfg256x192<true, true>, g2::EPI_GELU>(P, st);
     return g2::launch_cfg<g2::Cfg128x256<true, true>, g2::EPI_GELU>(P, st);
 }

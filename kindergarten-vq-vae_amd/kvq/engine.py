@@ -14,7 +14,8 @@ This engine runs the same mathematics as an explicit forward / backward schedule
   multi-GPU gradients are laid out in forward order, so backward finishes them from the end of the buffer towards
             the start: fixed-size tail chunks are all-reduced (RCCL, AVG, bf16) on a side stream while backward continues
 
-GEMMs go through torch.mm / addmm (hipBLASLt, bf16 in / f32 accumulate); everything else is libkvq.so.
+GEMMs: csrc/kvq_gemm2.hip for every shape of the bf16 step at >= 2048 tokens (the selection tables _OWN_*); f32 runs, small
+batches and the Gumbel quantiser's two products go through torch.mm / addmm (hipBLASLt).  Everything else is libkvq.so.
 Math restated from HuggingFace modeling_bert.py (see kvq/bert.py for the line map); tests/test_engine_gpu.py checks
 losses and every parameter gradient against the autograd path (kvq.bert + torch autograd).
 """
@@ -451,14 +452,19 @@ class TrainEngine:
 
     # (N, K) -> workgroup tile of csrc/kvq_gemm2.hip for the shapes where it beats the tuned library at 8192 rows
     # (tools/gemm2_probe.py on MI355X, interleaved rounds; gpurun_out/g2_probe*.log); every other shape stays with hipBLASLt
-    _OWN_FWD = {(768, 768): "128x192", (768, 3072): "128x192", (2304, 768): "128x192"}      # y = x . W^T + b        ("nt")
+    # "p" = the persistent tile loop (KVQ_GEMM_PERSISTENT): wherever a CU owns two or more tiles (tools/gemm2_probe_persist.py at
+    # round 3: QKV 37.4 -> 32.5 us, FFN1 42.9 -> 38.8, all-layer cross-K/V 216 -> 203 with column bands; library 36.8 / 45.4 / 196).
+    # The LM head keeps the one-tile kernel (354.7 us with column bands; persistent 362; library 344): with it the step has no
+    # vendor-library GEMM left.
+    _OWN_FWD = {(768, 768): "128x192", (768, 3072): "128x192", (2304, 768): "128x192p", (18432, 768): "256x256p",
+                (30528, 768): "256x256"}                                                    # y = x . W^T + b        ("nt")
     _OWN_DGRAD = {(768, 768): "128x192", (768, 2304): "128x192", (768, 3072): "128x192", (3072, 768): "256x192",
                   (768, 18432): "128x192", (768, 30528): "128x192"}                         # gx = gy . W            ("nn")
     # BertIntermediate / its backward with the activation inside the GEMM epilogue: (N, K) -> tile.  One v_exp_f32 + one v_rcp_f32
     # per element (Phi and phi share the exponential) and packed f32 FMAs; measured on MI355X (tools/gemm2_probe.py epi):
     # FFN1 forward 57.7 us against 44.5 + 19.3 (GEMM + gelu kernel), FFN2 backward 65.6 against 45.3 + 29.8; in the step
     # 19.07 -> 18.58 ms (gpurun_out/ab5.log).  KVQ_OWN_GELU="" / KVQ_OWN_DGELU="" switch back to the separate kernels.
-    _OWN_GELU = {(3072, 768): "256x192"}                                        # (h, gelu(h)) = x . W^T + b
+    _OWN_GELU = {(3072, 768): "256x192p"}                                       # (h, gelu(h)) = x . W^T + b
     _OWN_DGELU = {(3072, 768): "256x192"}                                       # (gy . W) * gelu'(h) + bias-gradient partials
     _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "256x192"}      # gW = gy^T . x          ("tn"), own launch
 

@@ -228,7 +228,8 @@ def embed_grad(g, perm, sorted_ids, gW, accumulate=False):
 
 # ---- the GEMM family of csrc/kvq_gemm2.hip ---------------------------------------------------------------------------------
 _LAYOUTS = {"nt": 0, "nn": 1, "tn": 2}
-TILES = {"128x192": 0, "128x256": 1, "256x192": 2, "256x256": 3}
+TILES = {"128x192": 0, "128x256": 1, "256x192": 2, "256x256": 3,
+         "128x192p": 0x100, "128x256p": 0x101, "256x192p": 0x102, "256x256p": 0x103}      # p: KVQ_GEMM_PERSISTENT (layout nt only)
 _TILE_DIMS = {0: (128, 192), 1: (128, 256), 2: (256, 192), 3: (256, 256)}
 
 

@@ -176,6 +176,59 @@ def test_multi_round_launches(layout, tile, shape):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("tile", ["128x192", "128x256", "256x192", "256x256"])
+@pytest.mark.parametrize("shape", [(8192, 3072, 768), (8192, 2304, 768), (2048, 30528, 768), (520, 1000, 192), (256, 256, 192),
+                                   (4104, 18432, 256)])
+def test_persistent_tile_loop_equals_the_one_tile_kernel(tile, shape):
+    """KVQ_GEMM_PERSISTENT (one workgroup per CU walks its tiles; the k-tiles of successive tiles are one LDS-DMA stream; the
+    accumulators go to memory from registers; edge tiles are pulled back inside the matrix): same bits as the one-tile-per-
+    workgroup kernel -- same summation order per element -- on 1 .. 30 tiles per CU, ragged M and N, strided output with a
+    canary frame, with and without bias; and both against an f32 matmul."""
+    from kvq import nnops
+    M, N, K = shape
+    a, b, ref = _ops("nt", M, N, K, seed=M + N + K + 1)
+    bias = torch.randn(N, device="cuda").to(torch.bfloat16)
+    for bv in (bias, None):
+        big = torch.full((M + 1, N + 24), 3.0, device="cuda", dtype=torch.bfloat16)
+        out = big[:M, 8:8 + N]
+        nnops.gemm(a, b, "nt", bias=bv, out=out, tile=tile + "p")
+        _check(out, ref + (bv.float() if bv is not None else 0.0), K)
+        assert (big[M] == 3).all() and (big[:, :8] == 3).all() and (big[:, 8 + N:] == 3).all()
+        one = nnops.gemm(a, b, "nt", bias=bv, tile=tile)
+        assert torch.equal(out, one)
+        again = nnops.gemm(a, b, "nt", bias=bv, tile=tile + "p")
+        assert torch.equal(again, one)
+
+
+@pytest.mark.parametrize("tile", ["256x192", "128x256"])
+def test_persistent_gemm_gelu_epilogue(tile):
+    from kvq import nnops
+    for (M, N, K) in [(8192, 3072, 768), (1032, 776, 256)]:
+        a, b, ref = _ops("nt", M, N, K, seed=7)
+        bias = torch.randn(N, device="cuda").to(torch.bfloat16)
+        h0, g0 = nnops.gemm_gelu(a, b, bias, tile=tile)
+        h1, g1 = nnops.gemm_gelu(a, b, bias, tile=tile + "p")
+        _check(h1, ref + bias.float(), K)
+        assert torch.equal(h1, h0) and torch.equal(g1, g0)
+
+
+def test_persistent_gemm_rejects_what_it_does_not_cover():
+    from kvq import nnops
+    from kvq._ffi import KvqError
+    a, b, _ = _ops("nn", 512, 512, 256)
+    with pytest.raises(KvqError):
+        nnops.gemm(a, b, "nn", tile="256x256p")                         # layout
+    a, b, _ = _ops("nt", 512, 512, 256)
+    with pytest.raises(KvqError):
+        nnops.gemm(a, b, "nt", out=torch.zeros((512, 512), device="cuda", dtype=torch.bfloat16), accumulate=True, tile="256x256p")
+    a, b, _ = _ops("nt", 128, 512, 256)
+    with pytest.raises(KvqError):
+        nnops.gemm(a, b, "nt", tile="256x256p")                         # less than one tile of rows
+    a, b, _ = _ops("nt", 512, 512, 64)
+    with pytest.raises(KvqError):
+        nnops.gemm(a, b, "nt", tile="128x256p")                         # fewer k-tiles than ring slots
+
+
 @pytest.mark.parametrize("M,N,V,K", [(296, 776, 770, 128), (512, 256, 256, 64), (2048, 30528, 30522, 768), (8192, 30528, 30522, 768)])
 def test_lm_head_gemm_with_loss_statistics(M, N, V, K):
     """kvq_gemm_bf16_ce + kvq_ce_forward_stats against the plain GEMM + kvq_ce_forward: the logits bit
