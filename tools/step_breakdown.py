@@ -22,8 +22,8 @@ for r in rows[a + 1:b + 1]:
 T = sum(v[0] for v in tot.values()) / 2
 walls = sorted((int(rows[ad[j + 1]]["End_Timestamp"]) - int(rows[ad[j]]["End_Timestamp"])) / 1e6 for j in range(max(0, len(ad) - 8), len(ad) - 1))
 wall = walls[len(walls) // 2]               # median of the last steps (the profiler's buffer flushes land in some of them)
-gemm = sum(v[0] for k, v in tot.items() if "gemm2" in k or "Cijk" in k) / 2e6
-own = sum(v[0] for k, v in tot.items() if "gemm2" in k) / 2e6
+gemm = sum(v[0] for k, v in tot.items() if "gemm2" in k or "gemm3" in k or "Cijk" in k) / 2e6
+own = sum(v[0] for k, v in tot.items() if "gemm2" in k or "gemm3" in k) / 2e6
 print(f"kernel time {T / 1e6:.3f} ms/step, wall {wall:.3f} ms/step, launches {sum(v[1] for v in tot.values()) // 2}, GEMM {gemm:.3f} ms (own {own:.3f})")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f"{v[0] / 2e6:7.3f} ms {v[1] // 2:4d} x {v[0] / v[1] / 1000:8.1f} us  {k}")
