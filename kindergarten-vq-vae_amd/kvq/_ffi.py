@@ -68,6 +68,9 @@ SIGNATURES = {
     "kvq_ln_bwd_partial_rows": (_i64, [_i64]),
     "kvq_dropout_residual_ln_bwd_partial": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp,
                                                    _int, _vp, _sz, _vp]),
+    "kvq_embed_ln_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _i64, _f32, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp,
+                                _vp, _vp, _vp]),
+    "kvq_ln_dropout_bwd_partial": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp, _sz, _vp]),
     "kvq_colsum_partial_rows": (_i64, [_i64]),
     "kvq_colsum_partial": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _sz, _vp]),
     "kvq_gelu_fwd": (_int, [_vp, _vp, _i64, _int, _vp]),

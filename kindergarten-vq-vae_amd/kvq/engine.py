@@ -172,11 +172,15 @@ class _StepGraphs:
     def __init__(self, eng, ids, mask):
         self.eng = eng
         dev = eng.dev
-        self.ids, self.mask = ids.clone(), mask.contiguous().clone()
+        # static input buffers the captured kernels read: ids | mask | ids sorted (stable, pads under -1) | their order
+        self.pack = eng.pack_batch(ids, mask)
+        self.ids, self.mask = self.pack[0].view(ids.shape), self.pack[1].view(ids.shape)
+        self.sorted = (self.pack[2], self.pack[3])
         N, H = ids.numel(), eng.H
         self.z_q = torch.empty((N, H), dtype=eng.dtype, device=dev)
         self.idx = torch.empty(N * max(eng.G, 1), dtype=torch.int64, device=dev)
-        self.vq_out = torch.empty(2, dtype=torch.float32, device=dev)
+        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)         # loss, accuracy | quantiser loss, perplexity: one clone per step
+        self.vq_out = self.scal[2:4]
         self.graphs, self.inter = [torch.cuda.CUDAGraph()], []
         side = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize(dev)
@@ -189,12 +193,14 @@ class _StepGraphs:
                 # thread-local capture mode: the process group's helper threads (gloo copies, the RCCL watchdog's event queries)
                 # keep issuing HIP calls on their own streams while this thread captures
                 self.graphs[0].capture_begin(capture_error_mode="thread_local")
+                eng._prepared = self.sorted
                 self.out = eng.forward_backward(self.ids, self.mask, training=eng.model.training, compute_grads=True, fuse_optimizer=True)
                 eng.optimizer_step()
                 self.graphs[-1].capture_end()
                 ok = True
             finally:
                 eng._cap = None
+                eng._prepared = None
                 eng._step_host = step0      # capturing ran no captured kernel: the device step state did not move either
                 if not ok:                  # close the capture that was open when the error struck
                     try:
@@ -214,15 +220,31 @@ class _StepGraphs:
         g.capture_begin(pool=self.graphs[0].pool(), capture_error_mode="thread_local")
         self.graphs.append(g)
 
-    def run(self, ids, mask):
-        self.ids.copy_(ids)
-        self.mask.copy_(mask)
+    def run(self, ids, mask, prepared=None):
+        if prepared is not None and prepared.shape == self.pack.shape:
+            self.pack.copy_(prepared)               # a batch packed where it was built (TrainEngine.pack_batch): one copy
+        else:                                       # otherwise the sort happens here -- outside the graphs, but in the step
+            self.ids.copy_(ids)
+            self.mask.copy_(mask)
+            srt, perm = self.eng.prepare_batch(ids)
+            self.sorted[0].copy_(srt)
+            self.sorted[1].copy_(perm)
         for i, g in enumerate(self.graphs):
             g.replay()
             if i < len(self.inter):
                 self.inter[i]()
         self.eng._step_host += 1
-        return {k: (v.clone() if v is not None else None) for k, v in self.out.items()}   # the graph's buffers are overwritten next step
+        # the graph's buffers are overwritten by the next step: hand out copies (the four scalars as views of ONE copy)
+        sc = self.scal.clone()
+        res = {}
+        for k, v in self.out.items():
+            if v is None:
+                res[k] = None
+            elif v.untyped_storage().data_ptr() == self.scal.untyped_storage().data_ptr():
+                res[k] = sc[v.storage_offset()]
+            else:
+                res[k] = v.clone()
+        return res
 
 
 class TrainEngine:
@@ -260,7 +282,7 @@ class TrainEngine:
         self._state = nnops.new_step_state(dev)
         self._step_host = 0
         self._step_seed = (self.seed * 1000003) & 0x7FFFFFFFFFFFFFF      # + step count on the device
-        self._graphs, self._eager_seen, self._cap = {}, {}, None
+        self._graphs, self._eager_seen, self._cap, self._prepared = {}, {}, None, None
         self._own_fwd = os.environ.get("KVQ_OWN_GEMM", "1") != "0"
         for attr, var in (("_OWN_FWD", "KVQ_OWN_FWD"), ("_OWN_DGRAD", "KVQ_OWN_DGRAD"), ("_OWN_GELU", "KVQ_OWN_GELU"),
                           ("_OWN_DGELU", "KVQ_OWN_DGELU"), ("_OWN_WGRAD_SINGLE", "KVQ_OWN_WGRAD_SINGLE")):
@@ -419,6 +441,8 @@ class TrainEngine:
         self._time_comm = False
         self._comm_ev = []                       # (start, end) event pairs around the points where the compute stream waits for RCCL
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
+        self._g_recon = torch.full((), self.w_recon, dtype=torch.float32, device=dev)     # d total / d loss term: constants of the run
+        self._g_vq = torch.full((), self.w_vq, dtype=torch.float32, device=dev)
         _load_gemm_tuning()
 
     # ------------------------------------------------------------------------------------------------------------
@@ -701,41 +725,43 @@ class TrainEngine:
     # blocks: forward returns (output, saved); backward consumes saved
     # ------------------------------------------------------------------------------------------------------------
     def _emb_fwd(self, prefix, cfg, ids, training, word_rows=None):
+        """BertEmbeddings (modeling_bert.py:53-110) as ONE kernel: gather + position / type rows + LayerNorm + dropout."""
         fl = self.flat
         B, S = ids.shape
         word = fl.w(prefix + "word", rows=word_rows) if word_rows else fl.w(prefix + "word")
-        y = F.embedding(ids.reshape(-1), word)                                           # [N,H]
-        pt = (fl.w(prefix + "pos")[:S] + fl.w(prefix + "type")[0]).repeat(B, 1)          # [N,H]
-        out, pre, mean, rstd = nnops.ln_fwd(y, pt, fl.w32(prefix + "ln.w"), fl.w32(prefix + "ln.b"), cfg.layer_norm_eps)
-        keep = None
         p = cfg.hidden_dropout_prob if training else 0.0
-        if p > 0:
-            keep = (p, self._site())                              # the mask is regenerated in backward from (seed, site)
-            out = nnops.dropout(out, p, self._step_seed, keep[1], out=out)
+        keep = (p, self._site()) if p > 0 else None               # the mask is regenerated in backward from (seed, site)
+        out, pre, mean, rstd = nnops.embed_ln_fwd(ids.reshape(-1), word, fl.w(prefix + "pos"), fl.w(prefix + "type")[0],
+                                                  fl.w32(prefix + "ln.w"), fl.w32(prefix + "ln.b"), cfg.layer_norm_eps, S,
+                                                  p, self._step_seed, keep[1] if keep else 0)
         return out, (ids, pre, mean, rstd, keep)
 
     def _emb_bwd(self, prefix, g, saved, tied_accumulate=False):
         fl = self.flat
         ids, pre, mean, rstd, keep = saved
         B, S = ids.shape
-        if keep is not None:
-            g = nnops.dropout(g, keep[0], self._step_seed, keep[1])
         tr = fl.trainable
-        g_y, g_pt = self._ln_bwd(g, pre, mean, rstd, fl.w32(prefix + "ln.w"), 0.0, 0, 0,
-                                 g_gamma=fl.g(prefix + "ln.w") if tr[prefix + "ln.w"] else None,
-                                 g_beta=fl.g(prefix + "ln.b") if tr[prefix + "ln.b"] else None)
+        # dropout(LayerNorm(x)): the mask applies to the incoming gradient, inside the LayerNorm backward kernel
+        g_y, part = nnops.ln_dropout_bwd_partial(g, pre, mean, rstd, fl.w32(prefix + "ln.w"), keep[0] if keep else 0.0,
+                                                 self._step_seed, keep[1] if keep else 0)
+        g_pt = g_y                                            # the sum's gradient reaches the word, position and type rows alike
+        Hn = g.shape[1]
+        gg, gb = (fl.g(prefix + "ln.w") if tr[prefix + "ln.w"] else None), (fl.g(prefix + "ln.b") if tr[prefix + "ln.b"] else None)
+        if gg is not None and gb is not None and gg.data_ptr() + Hn * gg.element_size() == gb.data_ptr():
+            self._defer(part, fl.fused([prefix + "ln.w", prefix + "ln.b"], fl.grad), part.shape[0], 2 * Hn, 3 * Hn, src_offset=Hn)
+        else:
+            if gg is not None:
+                self._defer(part, gg, part.shape[0], Hn, 3 * Hn, src_offset=Hn)
+            if gb is not None:
+                self._defer(part, gb, part.shape[0], Hn, 3 * Hn, src_offset=2 * Hn)
         if tr[prefix + "word"]:
             o, n, shape = fl.seg[prefix + "word"]
             gw = fl.grad[o:o + n].view(shape)
             if g_y.shape[1] % 4 == 0 and g_y.shape[1] <= 1024:
-                # deterministic segmented sum over the tokens sorted by id (one stable sort per step serves both tables)
+                # deterministic segmented sum over the tokens sorted by id: the order is a property of the BATCH, prepared once
+                # where the batch is built (prepare_batch: dsentences.token_cache / the trainer), not inside the replayed step
                 if self._sorted_ids is None:
-                    # nn.Embedding(padding_idx = pad token) of BertEmbeddings (modeling_bert.py:60): the pad row receives no
-                    # gradient from the lookups -- its tokens are sorted under id -1, which kvq_embed_grad ignores
-                    flat_ids = ids.reshape(-1)
-                    if self._pad_idx is not None:
-                        flat_ids = torch.where(flat_ids == self._pad_idx, torch.full_like(flat_ids, -1), flat_ids)
-                    self._sorted_ids = torch.sort(flat_ids, stable=True)
+                    self._sorted_ids = self.prepare_batch(ids)
                 if not tied_accumulate:
                     gw.zero_()
                 nnops.embed_grad(g_y, self._sorted_ids[1], self._sorted_ids[0], gw, accumulate=tied_accumulate)
@@ -976,7 +1002,8 @@ class TrainEngine:
         self._site_ctr = 0
         self._red_items, self._red_keep = [], []
         self._wg_items, self._wg_keep = [], []
-        self._sorted_ids = None
+        pre = getattr(self, "_prepared", None)                  # this batch's (sorted ids, order) -- or its pack_batch() tensor
+        self._sorted_ids = (pre[2], pre[3]) if torch.is_tensor(pre) else pre
         nnops.set_seed_offset(self._state)        # dropout seeds of this engine's launches = _step_seed + device step count
         try:
             self._q_training = training if quantizer_training is None else bool(quantizer_training)
@@ -1068,14 +1095,15 @@ class TrainEngine:
         row_loss = torch.empty(Nd, dtype=torch.float32, device=self.dev)
         row_lse = torch.empty(Nd, dtype=torch.float32, device=self.dev)
         pred = torch.empty(Nd, dtype=torch.int64, device=self.dev)
-        ce_out = torch.empty(2, dtype=torch.float32, device=self.dev)
+        ce_out = self._cap.scal[0:2] if (self._cap is not None and compute_grads) else torch.empty(2, dtype=torch.float32, device=self.dev)
         if lm_stats is not None:
             nnops.ce_forward_stats(logits, tgt, lm_stats, row_loss, row_lse, pred, ce_out[0:], ce_out[1:])
         else:
             check(lib().kvq_ce_forward(logits.data_ptr(), tgt.data_ptr(), Nd, self.V, self.Vp, self.io, row_loss.data_ptr(),
                                        row_lse.data_ptr(), pred.data_ptr(), ce_out[0:].data_ptr(), ce_out[1:].data_ptr(), stream_ptr()),
                   "kvq_ce_forward")
-        out = dict(loss_recon=ce_out[0] * self.w_recon, loss_vq=(loss_vq * self.w_vq) if self.has_vq else None,
+        out = dict(loss_recon=ce_out[0] if self.w_recon == 1.0 else ce_out[0] * self.w_recon,
+                   loss_vq=(loss_vq if self.w_vq == 1.0 else loss_vq * self.w_vq) if self.has_vq else None,
                    perplexity=perplexity, acc=ce_out[1], recon_ids=pred.view(B, Sd), indices=indices)
         if want_logits:
             out["logits"] = logits[:, :self.V].reshape(B, Sd, self.V)
@@ -1087,7 +1115,7 @@ class TrainEngine:
         if self._fuse_opt:      # lr / bias corrections of the step about to be applied; the step COUNT (dropout seed offset) stays
             nnops.step_state_advance(self._state, self.lr, self.gamma, self.milestones, self.betas[0], self.betas[1], phase="prepare")
         tr = fl.trainable
-        g_scale = self._ones * self.w_recon
+        g_scale = self._g_recon
         if tr["head.bias"] and self.Vp % 8 == 0:
             # in place: logits := d loss / d logits; the LM-head bias gradient leaves the same pass as partial column sums
             pb = torch.empty((lib().kvq_ce_bwd_partial_rows(N), self.Vp), dtype=torch.float32, device=self.dev)
@@ -1228,7 +1256,7 @@ class TrainEngine:
         gE = self.gE.data_ptr() if self.E.requires_grad else None
         if G == 1:
             g_z = torch.empty_like(z)
-            gl = self._ones * self.w_vq
+            gl = self._g_vq
             check(lib().kvq_vq_backward(z.data_ptr(), self.E.data_ptr(), idx.data_ptr(), g_enc.data_ptr(), gl.data_ptr(), N, K, H, 1,
                                         self.io, self.beta_vq, g_z.data_ptr(), gE, ws.data_ptr(), ws.numel(), stream_ptr()),
                   "kvq_vq_backward")
@@ -1386,24 +1414,44 @@ class TrainEngine:
         return kind in _QUANTIZERS + ("NoneType",) and cfg.hidden_size // cfg.num_attention_heads == 64 and seq_len <= 32 \
             and cfg.hidden_size % 32 == 0 and next(model.parameters()).is_cuda
 
-    def _train_step_eager(self, input_ids, attention_mask):
-        out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True, fuse_optimizer=True)
+    def prepare_batch(self, input_ids):
+        """What the word-embedding gradient needs besides the ids: the tokens in a STABLE order by id (sorted_ids, perm), pad
+        tokens filed under id -1 (nn.Embedding(padding_idx) of BertEmbeddings, modeling_bert.py:60: the pad row receives no
+        gradient; kvq_embed_grad ignores negative ids).  Part of building a batch -- hand the result to train_step(prepared=...)
+        (dsentences.token_cache does) and the step itself contains no sort; without it the engine sorts before the step."""
+        flat_ids = input_ids.reshape(-1)
+        if self._pad_idx is not None:
+            flat_ids = torch.where(flat_ids == self._pad_idx, torch.full_like(flat_ids, -1), flat_ids)
+        srt, perm = torch.sort(flat_ids, stable=True)
+        return srt, perm
+
+    def pack_batch(self, input_ids, attention_mask):
+        """ids | mask | sorted ids | order as ONE int64 tensor [4, B*S]: a replayed step then starts with one device copy."""
+        srt, perm = self.prepare_batch(input_ids)
+        return torch.stack([input_ids.reshape(-1), attention_mask.reshape(-1).to(torch.int64), srt, perm])
+
+    def _train_step_eager(self, input_ids, attention_mask, prepared=None):
+        self._prepared = prepared
+        try:
+            out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True, fuse_optimizer=True)
+        finally:
+            self._prepared = None
         self.optimizer_step()
         return out
 
-    def train_step(self, input_ids, attention_mask):
+    def train_step(self, input_ids, attention_mask, prepared=None):
         """One optimiser step.  Once a batch shape has been seen twice the step is replayed from a chain of hipGraphs
         (_StepGraphs: the quantiser and, on multi-GPU runs, the RCCL all-reduces stay eager launches between the graphs); the
         host then issues a handful of launches per step instead of ~800.  KVQ_GRAPH=0 keeps every launch eager."""
         if not self.use_graph:
-            return self._train_step_eager(input_ids, attention_mask)
+            return self._train_step_eager(input_ids, attention_mask, prepared)
         key = (tuple(input_ids.shape), bool(self.model.training))
         g = self._graphs.get(key)
         if g is None:
             seen = self._eager_seen.get(key, 0)
             if seen < 2 or len(self._graphs) >= 4:      # warm the workspaces / GEMM plans eagerly first; few shapes only
                 self._eager_seen[key] = seen + 1
-                return self._train_step_eager(input_ids, attention_mask)
+                return self._train_step_eager(input_ids, attention_mask, prepared)
             try:
                 g = self._graphs[key] = _StepGraphs(self, input_ids, attention_mask)
             except Exception as e:                       # capture is an optimisation: never let it take a run down
@@ -1411,8 +1459,8 @@ class TrainEngine:
                 print(f"[kvq] hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
                       f"continuing with eager launches", file=sys.stderr, flush=True)
                 self._abandon_capture()
-                return self._train_step_eager(input_ids, attention_mask)
-        return g.run(input_ids, attention_mask)
+                return self._train_step_eager(input_ids, attention_mask, prepared)
+        return g.run(input_ids, attention_mask, prepared)
 
     def _abandon_capture(self):
         """Leave a failed capture behind in a state from which eager steps can go on (same collectives, same order)."""

@@ -70,6 +70,33 @@ def ln_bwd_partial(g_out, pre, mean, rstd, gamma, p_drop=0.0, seed=0, site=0, ne
     return g_y, g_resid, part
 
 
+def embed_ln_fwd(ids, word, pos, type_row, gamma, beta, eps, seq_len, p_drop=0.0, seed=0, site=0):
+    """BertEmbeddings in one kernel: out = dropout(LayerNorm(word[ids] + pos[n % seq_len] + type_row)).
+    Returns (out, pre, mean, rstd) like ln_fwd; ids flat int64 [N]."""
+    require_gpu(ids, word, pos)
+    N, H = ids.numel(), word.shape[1]
+    out = torch.empty((N, H), dtype=word.dtype, device=word.device)
+    pre = torch.empty_like(out)
+    mean = torch.empty(N, dtype=torch.float32, device=word.device)
+    rstd = torch.empty(N, dtype=torch.float32, device=word.device)
+    check(lib().kvq_embed_ln_fwd(ids.data_ptr(), word.data_ptr(), pos.data_ptr(), type_row.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                 N, int(seq_len), H, word.shape[0], float(eps), float(p_drop), int(seed), int(site), io_dtype_of(word),
+                                 out.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), stream_ptr()), "kvq_embed_ln_fwd")
+    return out, pre, mean, rstd
+
+
+def ln_dropout_bwd_partial(g_out, pre, mean, rstd, gamma, p_drop, seed, site):
+    """Backward of dropout(LayerNorm(x)) (the embedding block): returns (g_x, part) with part [rows, 3H] f32 = [- | dgamma | dbeta]."""
+    N, H = g_out.shape
+    g_x = torch.empty_like(g_out)
+    l = lib()
+    part = torch.empty((l.kvq_ln_bwd_partial_rows(N), 3 * H), dtype=torch.float32, device=g_out.device)
+    check(l.kvq_ln_dropout_bwd_partial(g_out.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), N, H,
+                                       float(p_drop), int(seed), int(site), io_dtype_of(g_out), g_x.data_ptr(), part.data_ptr(),
+                                       part.numel() * 4, stream_ptr()), "kvq_ln_dropout_bwd_partial")
+    return g_x, part
+
+
 def colsum_partial(x, cols=None):
     """Per-workgroup partial column sums of a row-major 2-D tensor: part [rows, C] f32 (finish with reduce_batch())."""
     N = x.shape[0]

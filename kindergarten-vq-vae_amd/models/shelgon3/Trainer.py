@@ -46,7 +46,8 @@ def step(device, model, tokenizer, tokenizer_add_special_tokens: bool, opt,
     if engine is not None:
         # fast path: kvq.engine.TrainEngine runs forward, backward, gradient exchange and Adam (+ the per-step scheduler
         # tick) itself; the loss weights were given to its constructor
-        out = engine.train_step(input_ids, attention_mask) if opt is not None else engine.eval_step(input_ids, attention_mask)
+        out = engine.train_step(input_ids, attention_mask, prepared=batch.get("packed") if isinstance(batch, dict) else None) \
+            if opt is not None else engine.eval_step(input_ids, attention_mask)
         return {
             "loss_recon_step": out["loss_recon"].detach(), "loss_vq_step": out["loss_vq"].detach(),
             "metric_perp_step": out["perplexity"].detach(), "loss_full_step": (out["loss_recon"] + out["loss_vq"]).detach(),

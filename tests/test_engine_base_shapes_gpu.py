@@ -113,14 +113,16 @@ def test_engine_bf16_at_bert_base_shapes(monkeypatch):
     np.testing.assert_allclose(o1["loss_recon"], ref["loss_recon"], rtol=2e-2)
     np.testing.assert_allclose(o1["loss_vq"], ref["loss_vq"], rtol=5e-2)
     agree = (o1["idx"] == ref["idx"]).float().mean().item()
-    assert agree > 0.97, f"bf16 encoder output flips {100 * (1 - agree):.2f} % of the code indices"
+    assert agree > 0.975, f"bf16 encoder output flips {100 * (1 - agree):.2f} % of the code indices"      # measured 1.5 %
     cos = []
     for n, g in g1.items():
         r = ref["grads"][n]
         if r.norm() > 0 and not n.endswith("key.bias"):
             cos.append((n, F.cosine_similarity(g.reshape(-1), r.reshape(-1), dim=0).item()))
     worst = min(cos, key=lambda t: t[1])
-    assert worst[1] > 0.9 and np.mean([c for _, c in cos]) > 0.99, (worst, np.mean([c for _, c in cos]))
+    print("bf16 engine vs f32 autograd: worst gradient cosine", worst, "mean", np.mean([c for _, c in cos]), "code agreement", agree)
+    # measured on MI355X (round 3): worst 0.987 (the encoder's word-embedding table: sparse rows), mean 0.9991
+    assert worst[1] > 0.97 and np.mean([c for _, c in cos]) > 0.997, (worst, np.mean([c for _, c in cos]))
     # (b) own kernels against the library on the same bf16 inputs: only summation order differs
     np.testing.assert_allclose(o1["loss_recon"], o0["loss_recon"], rtol=2e-3)
     np.testing.assert_allclose(o1["loss_vq"], o0["loss_vq"], rtol=5e-3)
@@ -130,6 +132,83 @@ def test_engine_bf16_at_bert_base_shapes(monkeypatch):
         r = g0[n]
         err = (g - r).norm().item() / max(r.norm().item(), 1e-30)
         assert err < 3e-2, f"{n}: own-GEMM vs library relative L2 difference {err:.3g}"
+
+
+def test_every_own_gemm_of_the_engine_step_against_f32_matmul_of_its_operands(monkeypatch):
+    """Inside one bf16 engine step at bert-base widths every launch of the hand-written GEMM family (forward projections --
+    persistent and one-tile kernels --, input gradients incl. accumulate, the GELU / GELU' epilogues, single and grouped weight
+    gradients) is checked against an f32 matmul of the SAME bf16 operands it was given: the kernels inside the engine against
+    f32 truth, not against the vendor library and not only in isolation (tests/test_gemm2_gpu.py)."""
+    from kvq import nnops
+    from kvq.engine import TrainEngine
+    model = _build(torch.bfloat16)
+    eng = TrainEngine(model, lr=1e-4)
+    ids, mask = _batch(seed=8)
+    seen, worst = {"nt": 0, "nn": 0, "tn": 0, "gelu": 0, "dgelu": 0, "grouped": 0, "persistent": 0}, [0.0, ""]
+
+    def ref(a, b, layout):
+        a, b = a.float(), b.float()
+        return a @ b.t() if layout == "nt" else (a @ b if layout == "nn" else a.t() @ b)
+
+    def judge(out, want, what):
+        err = ((out.float() - want).norm() / want.norm().clamp_min(1e-30)).item()
+        if err > worst[0]:
+            worst[0], worst[1] = err, what
+        assert err < 4e-3, f"{what}: relative L2 error {err:.3g} against the f32 matmul of the same operands"     # bf16 output rounding: 2^-9
+
+    real = dict(gemm=nnops.gemm, gemm_gelu=nnops.gemm_gelu, gemm_dgelu=nnops.gemm_dgelu, gemm_problem=nnops.gemm_problem,
+                gemm_grouped=nnops.gemm_grouped)
+    recorded = {}
+
+    def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
+        before = out.float().clone() if accumulate else None
+        o = real["gemm"](a, b, layout, bias=bias, out=out, accumulate=accumulate, tile=tile)
+        want = ref(a, b, layout) + (bias.float() if bias is not None else 0.0)
+        if accumulate:
+            want = want.to(torch.bfloat16).float() + before
+        judge(o, want, f"gemm {layout} {tuple(o.shape)} K={a.shape[1] if layout != 'tn' else a.shape[0]} tile={tile} acc={accumulate}")
+        seen[layout] += 1
+        seen["persistent"] += isinstance(tile, str) and tile.endswith("p")
+        return o
+
+    def gemm_gelu(x, w, bias, tile="256x192"):
+        h, g = real["gemm_gelu"](x, w, bias, tile=tile)
+        judge(h, ref(x, w, "nt") + bias.float(), f"gemm_gelu h tile={tile}")
+        judge(g, F.gelu(h.float()), f"gemm_gelu gelu(h) tile={tile}")
+        seen["gelu"] += 1
+        seen["persistent"] += tile.endswith("p")
+        return h, g
+
+    def gemm_dgelu(gy, w, h, tile="256x192"):
+        g_h, part = real["gemm_dgelu"](gy, w, h, tile=tile)
+        with torch.enable_grad():                    # (the engine runs its schedule under no_grad)
+            hf = h.float().requires_grad_(True)
+            F.gelu(hf).backward(ref(gy, w, "nn").to(torch.bfloat16).float())
+        judge(g_h, hf.grad, "gemm_dgelu")
+        torch.testing.assert_close(part.sum(0), g_h.float().sum(0), rtol=1e-3, atol=2e-2)
+        seen["dgelu"] += 1
+        return g_h, part
+
+    def gemm_problem(a, b, out, layout, bias=None, accumulate=False):
+        pr = real["gemm_problem"](a, b, out, layout, bias=bias, accumulate=accumulate)
+        recorded[out.data_ptr()] = (a, b, out, layout)
+        return pr
+
+    def gemm_grouped(problems, layout, tile):
+        real["gemm_grouped"](problems, layout, tile)
+        for pr in problems:
+            a, b, out, lay = recorded.pop(pr.C)
+            judge(out, ref(a, b, lay), f"grouped {lay} {tuple(out.shape)} tile={tile}")
+            seen["grouped"] += 1
+
+    for k, f in dict(gemm=gemm, gemm_gelu=gemm_gelu, gemm_dgelu=gemm_dgelu, gemm_problem=gemm_problem, gemm_grouped=gemm_grouped).items():
+        monkeypatch.setattr(nnops, k, f)
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+    assert np.isfinite(out["loss_recon"].item()) and not recorded
+    print("own GEMM launches checked inside the engine step:", seen, "worst:", worst)
+    # 2 + 2 layers: every family ran, the persistent forward kernels included
+    assert seen["nt"] >= 12 and seen["nn"] >= 14 and seen["tn"] >= 2 and seen["gelu"] == 4 and seen["dgelu"] == 4
+    assert seen["grouped"] >= 20 and seen["persistent"] >= 8
 
 
 def test_engine_graph_step_at_bert_base_shapes_trains():

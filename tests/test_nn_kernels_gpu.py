@@ -56,6 +56,40 @@ def test_ln_fwd_bwd_no_dropout(ops, N, H, dtype):
     torch.testing.assert_close(gg2.float(), gr.grad + 1, rtol=2e-2, atol=2e-2 * scale)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,p", [(768, 0.1), (128, 0.0), (1024, 0.25)])
+def test_embedding_block_kernels_equal_the_separate_kernels(ops, dtype, H, p):
+    """BertEmbeddings (modeling_bert.py:53-110): kvq_embed_ln_fwd == gather + (pos + type) + kvq_dropout_residual_ln_fwd +
+    kvq_dropout bit for bit, and kvq_ln_dropout_bwd_partial == kvq_dropout on the gradient + the LayerNorm backward; the
+    composition itself is checked against torch (embedding, layer_norm, autograd) with dropout off."""
+    B, S, V = 9, 13, 500
+    torch.manual_seed(H + int(100 * p))
+    ids = torch.randint(0, V, (B, S), device="cuda")
+    word = torch.randn(V, H, device="cuda").to(dtype); pos = torch.randn(40, H, device="cuda").to(dtype)
+    typ = torch.randn(2, H, device="cuda").to(dtype)
+    gamma = torch.randn(H, device="cuda"); beta = torch.randn(H, device="cuda")
+    seed, site = 1234, 7
+    out, pre, mean, rstd = ops.embed_ln_fwd(ids.reshape(-1), word, pos, typ[0], gamma, beta, 1e-12, S, p, seed, site)
+    y = F.embedding(ids.reshape(-1), word)
+    pt = (pos[:S] + typ[0]).repeat(B, 1)
+    o2, pre2, mean2, rstd2 = ops.ln_fwd(y, pt, gamma, beta, 1e-12)
+    if p > 0:
+        o2 = ops.dropout(o2, p, seed, site)
+    assert torch.equal(pre, pre2) and torch.equal(out, o2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    g = torch.randn(B * S, H, device="cuda").to(dtype)
+    g_x, part = ops.ln_dropout_bwd_partial(g, pre, mean, rstd, gamma, p, seed, site)
+    gd = ops.dropout(g, p, seed, site) if p > 0 else g
+    g_y2, g_r2, part2 = ops.ln_bwd_partial(gd, pre, mean, rstd, gamma, 0.0, 0, 0)
+    assert torch.equal(g_x, g_y2) and torch.equal(part[:, H:], part2[:, H:])
+    if p == 0:
+        wr = word.float().requires_grad_(True)
+        ref = F.layer_norm((F.embedding(ids.reshape(-1), wr) + pt.float()).to(dtype).float(), (H,), gamma, beta, 1e-12)
+        torch.testing.assert_close(out.float(), ref, **_tol(dtype))
+    if p > 0:                                                  # the keep rate is the requested one
+        kept = (out != 0).float().mean().item()
+        assert abs(kept - (1 - p)) < 0.02
+
+
 def test_ln_dropout_mask_consistency(ops):
     """The mask is regenerated, not stored: forward and backward must see the same one, at the requested rate."""
     N, H, p = 512, 768, 0.1
