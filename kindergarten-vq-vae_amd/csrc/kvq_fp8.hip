@@ -3,9 +3,12 @@
 // Extension: the reference is f32 throughout; off unless the engine is built with fp8 forward GEMMs.
 //   y = x . W^T + b  (modeling_bert.py:139-352 behind models/bagon/Bagon.py:46-53)  becomes
 //   y = (sat(x * sx) . sat(W * sw)^T) / (sx * sw) + b   with sx = 448 / amax|x|, sw = 448 / amax|W| (448 = largest e4m3 value),
-// the scales computed from the tensor that is quantised, in the same step ("just-in-time" scaling: no amax history to keep or
-// to checkpoint).  Activations: two HBM-bound launches per GEMM input (amax, quantise).  Weights: the whole flat bf16 shadow
-// buffer in two launches per optimiser step, one scale per GEMM weight (a segment table maps buffer ranges to weights).
+// Weights: scales from the tensor that is quantised, in the same step (the whole flat bf16 shadow buffer in two launches per
+// optimiser step, one scale per GEMM weight; a segment table maps buffer ranges to weights).  Activations, as the engine uses
+// them: DELAYED scaling (kvq_fp8_quantize_delayed): one pass that quantises with the scale derived from the previous call's
+// amax at that site (4x headroom, kvq_fp8_update_scales) and records this call's amax; the first call at a site runs with
+// scale 1 and saturates at +-448.  kvq_fp8_quantize (amax pass + quantise pass, scale of the same tensor) is the two-launch
+// form without history.  A NaN stays a NaN through the quantisation (the clamp lets it pass), so a diverged activation shows.
 #include "kvq_common.h"
 
 namespace kvq {
@@ -13,7 +16,7 @@ namespace kvq {
 constexpr float FP8_MAX = 448.0f;
 constexpr int Q_THREADS = 256;
 
-__device__ __forceinline__ float amax8(const uint4 r) {
+__device__ __forceinline__ float amax8(const uint4 r) {          // (a NaN element does not enter the maximum: the scale stays usable)
     const unsigned w[4] = {r.x, r.y, r.z, r.w};
     float m = 0.f;
 #pragma unroll
@@ -30,8 +33,10 @@ __device__ __forceinline__ uint2 quant8(const uint4 r, float s) {
     float f[8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        f[2 * u] = fminf(fmaxf(__uint_as_float(w[u] << 16) * s, -FP8_MAX), FP8_MAX);
-        f[2 * u + 1] = fminf(fmaxf(__uint_as_float(w[u] & 0xffff0000u) * s, -FP8_MAX), FP8_MAX);
+        const float a = __uint_as_float(w[u] << 16) * s, b = __uint_as_float(w[u] & 0xffff0000u) * s;
+        // fminf / fmaxf return the non-NaN operand: clamp only what is a number, e4m3fn has a NaN encoding for the rest
+        f[2 * u] = a != a ? a : fminf(fmaxf(a, -FP8_MAX), FP8_MAX);
+        f[2 * u + 1] = b != b ? b : fminf(fmaxf(b, -FP8_MAX), FP8_MAX);
     }
     int lo = 0, hi = 0;
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);

@@ -423,7 +423,8 @@ class TrainEngine:
             if gq.n_embed > 1024:
                 raise KvqError("TrainEngine: the Gumbel row kernel holds at most 1024 codes")
             self.g_pw, self.g_pb, self.g_emb = add_aux(gq.proj.weight), add_aux(gq.proj.bias), add_aux(gq.embed.weight)
-        # extension (BASELINE.json configs[4], default off): forward GEMMs on the fp8 matrix cores, per-tensor just-in-time scales
+        # extension (BASELINE.json configs[4], default off): forward GEMMs on the fp8 matrix cores; per-tensor scales -- weights from
+        # the tensor itself after every update, activations delayed by one training step (kvq_fp8_quantize_delayed)
         self.fp8 = (os.environ.get("KVQ_FP8", "0") == "1") if fp8_forward is None else bool(fp8_forward)
         if self.fp8:
             if self.dtype != torch.bfloat16:
@@ -1011,7 +1012,10 @@ class TrainEngine:
                 if self.fp8:
                     self._a8_site = 0
                 out = self._forward_backward(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits)
-                if self.fp8:                 # next call's activation scales from this call's amax (4x headroom)
+                if self.fp8 and compute_grads:
+                    # the next TRAINING step's activation scales from this step's amax (4x headroom).  A forward-only call
+                    # (evaluation, Shelgon.forward) uses the scales as they are and leaves them alone: an eval batch must not
+                    # move the scales of the training step that follows it
                     check(lib().kvq_fp8_update_scales(self._a8_state.data_ptr(), self._a8_sites, 4.0, stream_ptr()), "kvq_fp8_update_scales")
                 return out
         finally:

@@ -207,7 +207,7 @@ def test_every_own_gemm_of_the_engine_step_against_f32_matmul_of_its_operands(mo
     assert np.isfinite(out["loss_recon"].item()) and not recorded
     print("own GEMM launches checked inside the engine step:", seen, "worst:", worst)
     # 2 + 2 layers: every family ran, the persistent forward kernels included
-    assert seen["nt"] >= 12 and seen["nn"] >= 14 and seen["tn"] >= 2 and seen["gelu"] == 4 and seen["dgelu"] == 4
+    assert seen["nt"] >= 12 and seen["nn"] >= 14 and seen["tn"] >= 1 and seen["gelu"] == 4 and seen["dgelu"] == 4
     assert seen["grouped"] >= 20 and seen["persistent"] >= 8
 
 

@@ -7,10 +7,15 @@ rm -rf "$out"; mkdir -p "$out"
 run() { name=$1; shift; timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -- python tools/gemm2_diag.py > "$out/$name.log" 2>&1; echo "$name done"; }
 run lat TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum
 run tlb TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum
-# (a third pass with TCC_EA0_* / TCC_TAG_STALL aborted rocprofv3 on this image -- signal 6 inside the tool -- and is not run)
+# TCC_EA0_* / TCC_TAG_STALL in ONE pass ask for more TCC counters than a pass holds ("Could not construct profile cfg failed with
+# error code 38: Request exceeds the capabilities of the hardware to collect", gpurun_out/gemm_diag/ea.log of round 2 -- the
+# abort was that, not a tool crash): one or two TCC counters per pass, as for FETCH_SIZE / WRITE_SIZE
+run ea_rd TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+run ea_wr TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
+run ea_stall TCC_EA0_WRREQ_STALL_sum TCC_TAG_STALL_sum
 python - <<'PY'
 import csv, glob, collections
-for p in ("lat", "tlb"):
+for p in ("lat", "tlb", "ea_rd", "ea_wr", "ea_stall"):
     f = glob.glob(f"gpurun_out/gemm_diag/{p}/*/*counter_collection.csv")
     if not f:
         print(p, "no output"); continue
