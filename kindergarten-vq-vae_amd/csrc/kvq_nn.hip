@@ -1786,16 +1786,24 @@ __device__ __forceinline__ void stage_transposed(unsigned* T, int r, int h, cons
         T[(j + 1) * AM_LDX + (r >> 1)] = (ev >> 16) | (od & 0xffff0000u);
     }
 }
-// C tile of a [d][row] product (row r on the lane, d = d_base + 8g + 4h + t in register 4g + t): four 8-byte stores
-// (8-byte stores, two lanes per 16 bytes of a row: the lines are completed by L2 write-combining.  Measured in round 2: without
-//  its stores attn_bwd runs 20.6 instead of 31.2 us, i.e. 10.6 us for 37.7 MB; the same stores with the streaming (nt) policy,
-//  which bypasses that combining, take the kernel to 80 us.)
+// C tile of a [d][row] product (row r on the lane, d = d_base + 8g + 4h + t in register 4g + t).  As it stands a lane holds four
+// separate 8-byte pieces of its row; the lane pair (r, h = 0 / 1) holds neighbouring pieces.  One v_permlane32_swap per dword
+// (lanes 32..63 of the first operand <-> lanes 0..31 of the second) trades piece 2j + 1 of the lower lane for piece 2j of the
+// upper one: the lower lane then owns d_base + 16j .. + 7, the upper lane d_base + 16j + 8 .. + 15 -- two 16-byte stores per
+// lane instead of four 8-byte ones (guide T21: a row-per-lane epilogue is store-ISSUE bound).  Round 2 measured the stores at
+// 10.6 of the backward kernel's 31 us for 37.7 MB; plain stores (the streaming policy, which bypasses L2's write combining,
+// took the kernel to 80 us).
 __device__ __forceinline__ void store_ct(void* base, size_t row_off, int h, int d_base, const f32x16& c) {
-    unsigned short* p = reinterpret_cast<unsigned short*>(base) + row_off + d_base + 4 * h;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned short* p = reinterpret_cast<unsigned short*>(base) + row_off + d_base + 8 * h;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        uint2 w = {pack_bf16(c[4 * g], c[4 * g + 1]), pack_bf16(c[4 * g + 2], c[4 * g + 3])};
-        *reinterpret_cast<uint2*>(p + 8 * g) = w;
+    for (int j = 0; j < 2; ++j) {
+        const unsigned xa = pack_bf16(c[8 * j], c[8 * j + 1]), xb = pack_bf16(c[8 * j + 2], c[8 * j + 3]);          // piece 2j
+        const unsigned ya = pack_bf16(c[8 * j + 4], c[8 * j + 5]), yb = pack_bf16(c[8 * j + 6], c[8 * j + 7]);      // piece 2j + 1
+        const u32x2 sa = __builtin_amdgcn_permlane32_swap(xa, ya, false, false);
+        const u32x2 sb = __builtin_amdgcn_permlane32_swap(xb, yb, false, false);
+        uint4 w = {sa.x, sb.x, sa.y, sb.y};
+        *reinterpret_cast<uint4*>(p + 16 * j) = w;
     }
 }
 // bias-gradient partial of one projection: sum_rows X[row][d] * w[row] for d = 32h + r, X from its pair-interleaved tile,

@@ -219,3 +219,40 @@ def test_bagon_forward_without_autograd_runs_on_the_engine_and_matches_huggingfa
         mb.decoder.cls.predictions.bias.add_(1.0)
         b = mb(enc_ids, enc_mask, enc_ids, enc_mask)
     assert (b.float() - a.float()).mean().item() > 0.9
+
+
+def test_engine_forward_sees_a_codebook_moved_by_the_module_ema_update():
+    """The autograd path with `ema_decay` moves the codebook through a raw pointer inside the module's forward (no tensor version
+    bump).  A following no_grad Shelgon.forward runs on the engine, which keeps a fragment-ordered copy of the codebook: the copy
+    must follow (VectorQuantizer.codebook_epoch; forward_logits repacks in any case) -- indices / loss / logits of the engine
+    forward equal the module path on the moved codebook."""
+    from kvq.engine import engine_of
+    from models.shelgon3.VectorQuantizer import VectorQuantizer
+    torch.manual_seed(3)
+    vq = VectorQuantizer(16, 128, 0.25, torch.randn(16, 128) * 0.5, ema_decay=0.5)
+    model = _model(vq).train()
+    ids, mask = _batch(B=8, S=16, seed=9)
+    with torch.no_grad():
+        model.eval()
+        model(ids, mask, "cuda", False)                        # builds the engine and its codebook pack from the INITIAL codebook
+        model.train()
+    eng = engine_of(model, create=False)
+    assert eng is not None and eng._epack is not None
+    E0 = vq.embedding.weight.detach().clone()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    for _ in range(2):                                          # two autograd steps: the module's forward moves the codebook
+        l_vq, _perp, _idx, l_rec, _acc, _recon = model.forward_loss(ids, mask)
+        opt.zero_grad(); (l_rec + l_vq).backward(); opt.step()
+    assert (vq.embedding.weight.detach() - E0).abs().max().item() > 1e-3 and vq.codebook_epoch == 2
+    model.eval()
+    with torch.no_grad():
+        l_e, p_e, idx_e, logits_e = model(ids, mask, "cuda", False)             # engine
+        z = model.encode(ids, mask)
+        l_m, zq_m, p_m, _enc, idx_m = vq.forward(z.contiguous(), "cuda")        # module path on the same encoder output
+    assert torch.equal(idx_e.reshape(-1), idx_m.reshape(-1))
+    torch.testing.assert_close(l_e.float(), l_m.float(), rtol=1e-5, atol=1e-7)
+    # and the stamp alone (without forward_logits' unconditional repack) notices the move
+    eng._repack_codebook()
+    stamp = eng._E_version
+    vq.ema_update(z.reshape(-1, 128).detach(), idx_m.reshape(-1))
+    assert eng._codebook_stamp() != stamp
