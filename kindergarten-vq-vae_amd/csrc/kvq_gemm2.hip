@@ -53,7 +53,9 @@ struct Problem {
     int lda, ldb, ldc;
     int tiles_m, tiles_n;
     int tile0;                         // first tile id of this problem in the launch
-    int band;                          // tile rows per band: inside a band tiles are numbered row-fastest (see the kernel)
+    int band;                          // > 0: tile rows per band, row-fastest inside a band; < 0: -band tile COLUMNS per band (see locate_tile)
+    unsigned mg_per_band, mg_full, mg_rem;   // division by multiplication (host-computed, exact for tile counts below 2^16): by the
+                                       // tiles of a band, by the width of a full band, by the width of the last, narrower band
     int accumulate;                    // C += result
     unsigned short* C2;                // EPI_GELU: second output gelu(C)
     const unsigned short* H;           // EPI_DGELU: pre-activation h [M, N] (row stride ldc); C = (A.B) * gelu'(h)
@@ -330,17 +332,41 @@ __device__ __forceinline__ void wait_vm() {
 struct TileId {
     int pi, tm, tn, m0, n0;
 };
-template <class C>
+// n / d for n, d < 2^16 with mg = 2^32 / d + 1: scalar multiply-high instead of the ~30-instruction v_rcp sequence hipcc emits
+// for an integer division (four of them sat between kernel entry and the first DMA of every workgroup)
+__device__ __forceinline__ int div_mg(int n, unsigned mg) { return mg ? (int)__umulhi((unsigned)n, mg) : n; }     // mg == 0: d == 1
+// (tm, tn) of local tile lt: bands of `band` tile rows (row-fastest inside) or of -band tile columns (column-fastest inside)
+__device__ __forceinline__ void band_walk(const Problem& pr, int lt, int& tm, int& tn) {
+    const bool colb = pr.band < 0;
+    const int w = colb ? -pr.band : pr.band;              // band width: tile columns (colb) or tile rows
+    const int across = colb ? pr.tiles_m : pr.tiles_n;    // tiles swept per unit of width
+    const int along = colb ? pr.tiles_n : pr.tiles_m;     // what the bands cut
+    const int per_band = w * across;
+    const int bnd = div_mg(lt, pr.mg_per_band), inb = lt - bnd * per_band;
+    const int o0 = bnd * w;
+    const bool last = along - o0 < w;                     // the last band may be narrower
+    const int wb = last ? along - o0 : w;
+    const int outer = div_mg(inb, last ? pr.mg_rem : pr.mg_full);
+    const int inner = o0 + inb - outer * wb;
+    tm = colb ? outer : inner;
+    tn = colb ? inner : outer;
+}
+template <class C, bool SINGLE = false>
 __device__ __forceinline__ TileId locate_tile(const Params& P, int id) {
     // XCD-aware numbering (bijective form), then problem lookup
     {
         const int nt = P.ntiles, q = nt >> 3, r = nt & 7, x = id & 7;
         id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
     }
+    // One problem (every launch but the grouped weight gradients): its fields sit at fixed kernel-argument offsets and are
+    // requested in one batch at kernel entry.  Several: the tile0 look-up and then the chosen problem's fields are two more
+    // dependent trips to the scalar cache.
     int pi = 0;
+    if constexpr (!SINGLE) {
 #pragma unroll
-    for (int i = 1; i < MAX_PROBLEMS; ++i)
-        if (i < P.nprob && id >= P.p[i].tile0) pi = i;
+        for (int i = 1; i < MAX_PROBLEMS; ++i)
+            if (i < P.nprob && id >= P.p[i].tile0) pi = i;
+    }
     const Problem& pr = P.p[pi];
     // Tile order inside the problem: bands of `band` tile rows, row-fastest inside a band: the tiles an XCD runs together share
     // `band` A tile rows (resident in its 4 MiB L2) and each B tile is fetched once per band instead of once per tile row
@@ -348,25 +374,11 @@ __device__ __forceinline__ TileId locate_tile(const Params& P, int id) {
     const int lt = id - pr.tile0;
     TileId t;
     t.pi = pi;
-    if (pr.band < 0) {
-        // column bands (wide outputs): -band tile COLUMNS per band, column-fastest inside a band, every tile row swept per band.
-        // The band's B tiles (-band x BN x K x 2 bytes: <= 3 MiB) stay in the XCD's L2 while the A row tiles stream past once
-        // per band; with row bands every XCD re-reads ALL of B once per band of rows (LM head: 16 x 47 MB from the fabric)
-        const int wc = -pr.band;
-        const int per_band = wc * pr.tiles_m;
-        const int bnd = lt / per_band, inb = lt - bnd * per_band;
-        const int c0 = bnd * wc;
-        const int cb = pr.tiles_n - c0 < wc ? pr.tiles_n - c0 : wc;
-        t.tm = inb / cb;
-        t.tn = c0 + inb - t.tm * cb;
-    } else {
-        const int per_band = pr.band * pr.tiles_n;
-        const int bnd = lt / per_band, inb = lt - bnd * per_band;
-        const int r0 = bnd * pr.band;
-        const int rb = pr.tiles_m - r0 < pr.band ? pr.tiles_m - r0 : pr.band;
-        t.tn = inb / rb;
-        t.tm = r0 + inb - t.tn * rb;
-    }
+    // Tile order inside the problem.  band > 0: bands of `band` tile rows, row-fastest inside (band = 1: column-fastest).
+    // band < 0 (wide outputs): -band tile COLUMNS per band, column-fastest inside, every tile row swept per band: the band's B
+    // tiles (<= 3 MiB) stay in the XCD's L2 while the A row tiles stream past once per band; with row bands every XCD re-reads
+    // ALL of B once per band of rows (LM head: 16 x 47 MB from the fabric)
+    band_walk(pr, lt, t.tm, t.tn);
     t.m0 = t.tm * C::BM;
     t.n0 = t.tn * C::BN;
     return t;
@@ -375,13 +387,18 @@ __device__ __forceinline__ TileId locate_tile(const Params& P, int id) {
 // the bias values this lane will add in the epilogue: requested at kernel start, FB dependent round trips to L2 later otherwise
 template <class C>
 __device__ __forceinline__ void load_bias(const Problem& pr, int n0, int wn, int lane, u16x4 (&biasv)[C::FB]) {
+    // No branch around a load: hipcc would wait vmcnt(0) behind each of them (three dependent round trips to L2 at the start of
+    // every workgroup: 1.5 of the 2.7 us the stamps showed between kernel entry and the first DMA).  Without a bias the loads
+    // read the first elements of B (always there, N of them at least) and the values are masked to zero.
     const int fk0 = lane >> 4;
+    const unsigned short* bp = pr.bias ? pr.bias : pr.B;
+    const unsigned short keep = pr.bias ? 0xffffu : 0u;
 #pragma unroll
     for (int ni = 0; ni < C::FB; ++ni) {
         int nb = n0 + wn * C::TN + ni * 16 + 4 * fk0;
         nb = nb + 4 <= pr.N ? nb : pr.N - 4;
-        const u16x4 zero = {0, 0, 0, 0};
-        biasv[ni] = pr.bias ? *reinterpret_cast<const u16x4*>(pr.bias + nb) : zero;
+        const u16x4 t = *reinterpret_cast<const u16x4*>(bp + nb);
+        biasv[ni] = u16x4{(unsigned short)(t.x & keep), (unsigned short)(t.y & keep), (unsigned short)(t.z & keep), (unsigned short)(t.w & keep)};
     }
 }
 
@@ -612,7 +629,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
     __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring is free (it becomes the epilogue tile)
 }
 
-template <class C, int EPI>
+template <class C, int EPI, bool SINGLE>
 __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     G2_STAMP(0);
@@ -621,8 +638,8 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / C::WN, wn = w % C::WN;
-    const TileId ti = locate_tile<C>(P, blockIdx.x);
-    const Problem& pr = P.p[ti.pi];
+    const TileId ti = locate_tile<C, SINGLE>(P, blockIdx.x);
+    const Problem& pr = P.p[SINGLE ? 0 : ti.pi];
     const int m0 = ti.m0, n0 = ti.n0;
     const int nkt = pr.K / BK;
 
@@ -637,9 +654,12 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
     // ---- prologue: fill the ring
     Stager<C> sg;
     sg.init(pr, smem, m0, n0, w, lane);
+    G2_STAMP(10);
 #pragma unroll
-    for (int s = 0; s < C::NS; ++s)
+    for (int s = 0; s < C::NS; ++s) {
         if (s < nkt) sg.issue(s);
+        if (s == 0) G2_STAMP(11);
+    }
     G2_STAMP(3);
     mainloop<C>(acc, sg, smem, nkt, wm, wn, lane);
     G2_STAMP(5);
@@ -688,22 +708,7 @@ __device__ __forceinline__ void tile_origin(const Params& P, int id, int& m0, in
     const int nt = P.ntiles, q = nt >> 3, r = nt & 7, x = id & 7;
     id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);                 // XCD-aware numbering (see locate_tile)
     int tm, tn;
-    if (pr.band < 0) {
-        const int wc = -pr.band;
-        const int per_band = wc * pr.tiles_m;
-        const int bnd = id / per_band, inb = id - bnd * per_band;
-        const int c0 = bnd * wc;
-        const int cb = pr.tiles_n - c0 < wc ? pr.tiles_n - c0 : wc;
-        tm = inb / cb;
-        tn = c0 + inb - tm * cb;
-    } else {
-        const int per_band = pr.band * pr.tiles_n;
-        const int bnd = id / per_band, inb = id - bnd * per_band;
-        const int r0 = bnd * pr.band;
-        const int rb = pr.tiles_m - r0 < pr.band ? pr.tiles_m - r0 : pr.band;
-        tn = inb / rb;
-        tm = r0 + inb - tn * rb;
-    }
+    band_walk(pr, id, tm, tn);
     m0 = tm * C::BM < pr.M - C::BM ? tm * C::BM : pr.M - C::BM;
     n0 = tn * C::BN < pr.N - C::BN ? tn * C::BN : pr.N - C::BN;
 }
@@ -954,8 +959,8 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_f8_kernel(Para
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / C::WN, wn = w % C::WN;
-    const TileId ti = locate_tile<C>(P, blockIdx.x);
-    const Problem& pr = P.p[ti.pi];
+    const TileId ti = locate_tile<C, true>(P, blockIdx.x);
+    const Problem& pr = P.p[0];
     const int m0 = ti.m0, n0 = ti.n0;
     const int nkt = pr.K / BK;                 // K counted in bf16-sized units (= 2 fp8 elements): 64 units = 128 bytes per row
 
@@ -1024,16 +1029,23 @@ template <bool AK, bool BKM> using Cfg128x192 = Cfg<128, 192, 2, 4, AK, BKM, 3>;
 template <bool AK, bool BKM> using Cfg256x256 = Cfg<256, 256, 2, 4, AK, BKM, 2>;     // 8 waves, 128 KiB
 template <bool AK, bool BKM> using Cfg128x192p = Cfg<128, 192, 4, 2, AK, BKM, 3>;    // persistent form: an even number of 16-column blocks per wave
 
-template <class C, int EPI = EPI_NONE>
-static int launch_cfg(const Params& P, hipStream_t st) {
+template <class C, int EPI, bool SINGLE>
+static int launch_cfg1(const Params& P, hipStream_t st) {
     static std::atomic<bool> attr_done{false};      // per instantiation; idempotent, so a race only repeats the call
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<C, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<C, EPI, SINGLE>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm2): %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm2_kernel<C, EPI>), dim3((unsigned)P.ntiles), dim3(C::THREADS), C::LDS, st, P);
+    hipLaunchKernelGGL((gemm2_kernel<C, EPI, SINGLE>), dim3((unsigned)P.ntiles), dim3(C::THREADS), C::LDS, st, P);
     return check_launch("gemm2_kernel");
+}
+template <class C, int EPI = EPI_NONE>
+static int launch_cfg(const Params& P, hipStream_t st) {
+    if constexpr (EPI == EPI_NONE) {
+        if (P.nprob > 1) return launch_cfg1<C, EPI, false>(P, st);      // (the epilogue variants are single-problem entry points)
+    }
+    return launch_cfg1<C, EPI, true>(P, st);
 }
 
 static int persistent_grid() {
@@ -1124,6 +1136,14 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
         if (getenv("KVQ_GEMM_BAND") && atoi(getenv("KVQ_GEMM_BAND")) != 0) d.band = atoi(getenv("KVQ_GEMM_BAND"));
         if (d.band > d.tiles_m) d.band = d.tiles_m;
         if (-d.band > d.tiles_n) d.band = -d.tiles_n;
+        {
+            const int w = d.band < 0 ? -d.band : d.band, across = d.band < 0 ? d.tiles_m : d.tiles_n, along = d.band < 0 ? d.tiles_n : d.tiles_m;
+            KVQ_REQUIRE(d.tiles_m * d.tiles_n < 65536 && w * across < 65536, "%s: problem %d: more than 65535 tiles", who, i);
+            auto mg = [](int dv) { return dv > 1 ? (unsigned)(0x100000000ull / (unsigned)dv + 1) : 0u; };      // 0 = divide by one
+            d.mg_per_band = mg(w * across);
+            d.mg_full = mg(w);
+            d.mg_rem = mg(along % w ? along % w : w);
+        }
         d.C2 = nullptr; d.H = nullptr; d.part = nullptr; d.vlimit = 0; d.scaleA = nullptr; d.scaleB = nullptr;
         t0 += d.tiles_m * d.tiles_n;
     }

@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libkvq.so")
+# KVQ_LIB_PATH: another build of the same library (A/B runs of two builds on one GPU box, the diagnostic build of tools/); the load
+# still fails loudly when the file is missing
+LIB_PATH = os.environ.get("KVQ_LIB_PATH") or os.path.join(_PKG, "lib", "libkvq.so")
 
 KVQ_F32, KVQ_BF16 = 0, 1
 

@@ -74,7 +74,9 @@ def us(d):
     return d / (np.median(clk) * 1e3)
 
 
-for name, d in (("entry -> ring issued", t_issued - t_entry), ("ring issued -> first k-tile landed", t_first - t_issued),
+t_setup, t_k0 = s[:, 10], s[:, 11]
+for name, d in (("  entry -> setup done (tile lookup, bias, offsets)", t_setup - t_entry), ("  setup done -> k-tile 0 issued", t_k0 - t_setup),
+                ("  k-tile 0 issued -> ring issued", t_issued - t_k0), ("entry -> ring issued", t_issued - t_entry), ("ring issued -> first k-tile landed", t_first - t_issued),
                 ("main loop", t_loop - t_first), ("accumulators -> LDS (+barrier)", t_lds - t_loop),
                 ("LDS -> store instructions issued", t_st - t_lds), ("stores issued -> stores done", t_done - t_st)):
     print(f"  {name:38s} median {np.median(us(d)):6.2f} us   p10 {np.percentile(us(d), 10):6.2f}   p90 {np.percentile(us(d), 90):6.2f}")
