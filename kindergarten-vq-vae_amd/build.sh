@@ -4,7 +4,9 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 mkdir -p "$here/lib"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -I"$here/../include" -I"$here/csrc" -Wall -Wno-unused-function)
+# -amdgpu-kernarg-preload-count: the first 16 dwords of scalar kernel arguments arrive in SGPRs with the wave (no s_load round trip
+# before the first address is known); kernels whose arguments are one by-value struct are unaffected.  Same-box A/B: -0.06 ms/step.
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -mllvm -amdgpu-kernarg-preload-count=16 -I"$here/../include" -I"$here/csrc" -Wall -Wno-unused-function)
 objs=()
 for src in "$here"/csrc/*.hip; do
   obj="$here/lib/$(basename "${src%.hip}").o"

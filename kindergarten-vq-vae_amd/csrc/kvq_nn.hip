@@ -65,30 +65,52 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
                                                         unsigned site, void* __restrict__ out,
                                                         void* __restrict__ pre, float* __restrict__ mean_out,
                                                         float* __restrict__ rstd_out) {
-    if (seed_off) seed += *seed_off;          // device-resident step counter: a captured graph replays with fresh masks
+    // EVERY load of the row is requested before anything is done with one of them, and no load sits behind a branch: chunk
+    // indices past the row are clamped (and masked out of the sums), a missing residual reads y again and is weighted 0.
+    // As first written ("if (c < nchunk) { load y; ...; if (resid) load resid; ... }" per chunk) hipcc put s_waitcnt vmcnt(0)
+    // behind each load: six dependent trips to memory per row, then three more for gamma / beta -- 13.3 us for the 50 MB of a
+    // [8192, 768] call, one round of waves doing nothing but waiting (ISA audit of round 3).
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
     const int nchunk = H >> 2;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    f32x4 v[PER];
+    const void* rp = resid ? resid : y;
+    const float rw = resid ? 1.0f : 0.0f;
+    constexpr bool EARLY_GB = PER <= 4;        // (wide rows: gamma / beta stay L2-resident small loads of the last pass)
+    f32x4 v[PER], r[PER], g[EARLY_GB ? PER : 1], b[EARLY_GB ? PER : 1];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int c = lane + WAVE * t < nchunk ? lane + WAVE * t : nchunk - 1;
+        const size_t off = (size_t)row * H + 4 * c;
+        v[t] = IO<DT>::load4(y, off);
+        r[t] = IO<DT>::load4(rp, off);
+    }
+    if constexpr (EARLY_GB) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int c = lane + WAVE * t < nchunk ? lane + WAVE * t : nchunk - 1;
+            g[t] = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
+            b[t] = *reinterpret_cast<const f32x4*>(beta + 4 * c);
+        }
+    }
+    if (seed_off) seed += *seed_off;          // device-resident step counter (a captured graph replays with fresh masks): the
+                                              // dependent scalar load waits while the row is on its way
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int c = lane + WAVE * t;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        f32x4 a = v[t];
+        if (p_drop > 0.f) {                   // (uniform; arithmetic only: the Philox rounds run while the loads are in flight)
+            const U4 kb = drop_bits(seed, site, (unsigned long long)row * nchunk + c);
+            a.x *= keep_scale(kb.x, thresh, inv_keep); a.y *= keep_scale(kb.y, thresh, inv_keep);
+            a.z *= keep_scale(kb.z, thresh, inv_keep); a.w *= keep_scale(kb.w, thresh, inv_keep);
+        }
+        a += r[t] * rw;
+        // LayerNorm sees the STORED pre-activation (bf16-rounded when io is bf16): backward re-reads exactly that
+        a.x = IO<DT>::round(a.x); a.y = IO<DT>::round(a.y); a.z = IO<DT>::round(a.z); a.w = IO<DT>::round(a.w);
         if (c < nchunk) {
-            const size_t off = (size_t)row * H + 4 * c;
-            a = IO<DT>::load4(y, off);
-            if (p_drop > 0.f) {
-                const U4 b = drop_bits(seed, site, (unsigned long long)row * nchunk + c);
-                a.x *= keep_scale(b.x, thresh, inv_keep); a.y *= keep_scale(b.y, thresh, inv_keep);
-                a.z *= keep_scale(b.z, thresh, inv_keep); a.w *= keep_scale(b.w, thresh, inv_keep);
-            }
-            if (resid) a += IO<DT>::load4(resid, off);
-            // LayerNorm sees the STORED pre-activation (bf16-rounded when io is bf16): backward re-reads exactly that
-            a.x = IO<DT>::round(a.x); a.y = IO<DT>::round(a.y); a.z = IO<DT>::round(a.z); a.w = IO<DT>::round(a.w);
-            if (pre) IO<DT>::store4(pre, off, a);
+            if (pre) IO<DT>::store4(pre, (size_t)row * H + 4 * c, a);
             sum += (a.x + a.y) + (a.z + a.w);
         }
         v[t] = a;
@@ -108,9 +130,10 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
     for (int t = 0; t < PER; ++t) {
         const int c = lane + WAVE * t;
         if (c < nchunk) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c);
-            const f32x4 o = (v[t] - mean) * rstd * g + b;
+            f32x4 gg, bb;
+            if constexpr (EARLY_GB) { gg = g[t]; bb = b[t]; }
+            else { gg = *reinterpret_cast<const f32x4*>(gamma + 4 * c); bb = *reinterpret_cast<const f32x4*>(beta + 4 * c); }
+            const f32x4 o = (v[t] - mean) * rstd * gg + bb;
             IO<DT>::store4(out, (size_t)row * H + 4 * c, o);
         }
     }
