@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "kvq_common.h"
 
@@ -603,29 +604,38 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
     constexpr int PH = C::NS == 2 ? C::PPW : C::PPW / 2;
     int slot = 0, pslot = 0;
     bool pending = false;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // One k-tile.  STEADY = a refill is pending on entry, another k-tile follows and another refill starts: true for every
+    // k-tile but the first and the last NS.  With these three as compile-time constants the clusters carry no branch around
+    // the DMA pieces (as run-time flags each piece sat behind an s_cbranch plus the v_cndmask / v_cmp pair hipcc builds for a
+    // uniform bool: a basic-block cut every four or five MFMAs)
+    auto ktile = [&](int kt, auto steady) {
+        constexpr bool STEADY = decltype(steady)::value;
         const char* st = smem + slot * C::STAGE;
         __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): f0 (its reads ended half a cluster ago)
         __builtin_amdgcn_sched_barrier(0);
-        mma<C, PH, C::PPW>(acc, f0, f1, st, 1, wm, wn, lane, sg, pslot, pending);
-        if (pending) sg.advance();
+        mma<C, PH, C::PPW>(acc, f0, f1, st, 1, wm, wn, lane, sg, pslot, STEADY ? true : pending);
+        if (STEADY || pending) sg.advance();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);                                // f1 arrived: this wave is done with `slot`
         pending = false;
-        const bool more = kt + 1 < nkt;
+        const bool more = STEADY || kt + 1 < nkt;
         const int nslot = slot + 1 == C::NS ? 0 : slot + 1;
         if (more) {
-            if (kt + C::NS <= nkt) wait_vm<(C::NS - 2) * C::PPW>();         // tiles kt+2 .. kt+NS-1 may still be in flight
+            if (STEADY || kt + C::NS <= nkt) wait_vm<(C::NS - 2) * C::PPW>();   // tiles kt+2 .. kt+NS-1 may still be in flight
             else wait_vm<0>();
             __builtin_amdgcn_s_barrier();                                  // tile kt+1 landed for everybody; `slot` is free
-            pending = kt + C::NS < nkt;
+            pending = STEADY || kt + C::NS < nkt;
             pslot = slot;
         }
         __builtin_amdgcn_sched_barrier(0);
         // (after the last k-tile this still reads a ring slot -- stale bytes, inside the ring, never used)
-        mma<C, 0, PH>(acc, f1, f0, smem + nslot * C::STAGE, 0, wm, wn, lane, sg, pslot, pending);
+        mma<C, 0, PH>(acc, f1, f0, smem + nslot * C::STAGE, 0, wm, wn, lane, sg, pslot, STEADY ? true : pending);
         slot = nslot;
-    }
+    };
+    int kt = 0;
+    if (nkt > 0) ktile(kt++, std::false_type{});
+    for (; kt + C::NS < nkt; ++kt) ktile(kt, std::true_type{});
+    for (; kt < nkt; ++kt) ktile(kt, std::false_type{});
     __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring is free (it becomes the epilogue tile)
 }
 

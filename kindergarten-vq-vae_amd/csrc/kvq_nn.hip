@@ -664,8 +664,12 @@ __device__ __forceinline__ void reduce_tree_block(const kvq_reduce_item& d, int 
 
 __global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceBatch rb) {
     __shared__ float red[16][64];
+    // which item: first_block[] is increasing, so the index is a COUNT -- every comparison independent of the others, all
+    // table entries requested in one batch (a `while` over the table is a chain of up to 32 dependent scalar loads at the start
+    // of every workgroup)
     int i = 0;
-    while (i + 1 < rb.n && (int)blockIdx.x >= rb.first_block[i + 1]) ++i;      // block-uniform
+#pragma unroll
+    for (int k = 1; k < KVQ_REDUCE_MAX_ITEMS; ++k) i += (k < rb.n && (int)blockIdx.x >= rb.first_block[k]) ? 1 : 0;
     const kvq_reduce_item& d = rb.it[i];
     const int blk = (int)blockIdx.x - rb.first_block[i];
     const int combo = (d.src_dtype == KVQ_F32 ? 0 : 2) | (d.dst_dtype == KVQ_F32 ? 0 : 1);

@@ -491,7 +491,8 @@ class TrainEngine:
     # 19.07 -> 18.58 ms (gpurun_out/ab5.log).  KVQ_OWN_GELU="" / KVQ_OWN_DGELU="" switch back to the separate kernels.
     _OWN_GELU = {(3072, 768): "256x192p"}                                       # (h, gelu(h)) = x . W^T + b
     _OWN_DGELU = {(3072, 768): "256x192"}                                       # (gy . W) * gelu'(h) + bias-gradient partials
-    _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "256x192"}      # gW = gy^T . x          ("tn"), own launch
+    _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "128x256"}      # gW = gy^T . x          ("tn"), own launch
+    # (LM-head weight gradient: 128x256 329 us, 256x192 354, 256x256 373 in tools/gemm2_probe.py at round 3)
 
     # ---- fp8 forward GEMMs -------------------------------------------------------------------------------------------------
     def _fp8_setup(self):
