@@ -57,9 +57,28 @@ out += ["", "MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SI
             "2NKD / 64 FLOP-per-clock = 1.007e8 cycles: no redundant matrix work.", ""]
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(out))
 dk = [k for k in traffic if "dist_packed" in k]
+# the large-codebook point (BASELINE.json configs[3], K = 8192): traffic passes only
+agg8 = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ["pmc_fetch_k8192", "pmc_write_k8192"]:
+    f = glob.glob(f"{run}/{d}/*/*_counter_collection.csv")
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            if "vq_" in r["Kernel_Name"]:
+                agg8[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+traffic8 = {k: (2 * sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1) + sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)) * 1024
+            for k, c in agg8.items() if c.get("FETCH_SIZE") and c.get("WRITE_SIZE")}
+if traffic8:
+    out += ["", "## K = 8192 (BASELINE.json configs[3]): fabric traffic of the quantiser kernels, same recipe with VQ_K=8192", "",
+            "| kernel | corrected fabric MB per launch |", "|---|---|"] + [f"| `{k}` | {v / 1e6:.1f} |" for k, v in traffic8.items()]
+    open(f"profiles/{tag}_summary.md", "w").write("\n".join(out))
 if dk:
     fwd = {k: traffic[k] for k in traffic if any(t in k for t in ("dist_packed", "vq_epilogue", "vq_finalize"))}
-    json.dump({"N8192_K512_D768_bfloat16": traffic[dk[0]], "_kernel": dk[0], "forward_kernels_N8192_K512_D768_bfloat16": fwd,
+    extra = {}
+    dk8 = [k for k in traffic8 if "dist_packed" in k]
+    if dk8:
+        extra = {"N8192_K8192_D768_bfloat16": traffic8[dk8[0]],
+                 "forward_kernels_N8192_K8192_D768_bfloat16": {k: traffic8[k] for k in traffic8 if any(t in k for t in ("dist_packed", "vq_epilogue", "vq_finalize"))}}
+    json.dump({"N8192_K512_D768_bfloat16": traffic[dk[0]], "_kernel": dk[0], "forward_kernels_N8192_K512_D768_bfloat16": fwd, **extra,
                "_source": f"profiles/{tag}_summary.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                           f"launch; the factor 2 on FETCH_SIZE holds for 4-, 8- and 16-byte loads per lane alike (calibration in profiles/{tag}_gemm_pmc.md)"},
               open("profiles/vq_fwd_traffic.json", "w"), indent=1)

@@ -16,5 +16,9 @@ echo "traffic passes done"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$out/pmc_sq" -- python tools/vq_only.py > "$out/pmc_sq.log" 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/pmc_grbm" -- python tools/vq_only.py > "$out/pmc_grbm.log" 2>&1
 echo "counter passes done"
+# the large-codebook point (BASELINE.json configs[3]): fabric traffic of the quantiser kernels at K = 8192
+VQ_K=8192 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_k8192" -- python tools/vq_only.py > "$out/pmc_fetch_k8192.log" 2>&1
+VQ_K=8192 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_k8192" -- python tools/vq_only.py > "$out/pmc_write_k8192.log" 2>&1
+echo "K = 8192 traffic passes done"
 timeout -k 10 300 python bench.py > "$out/bench_line.json" 2> "$out/bench.err"
 tail -c 600 "$out/bench_line.json"
