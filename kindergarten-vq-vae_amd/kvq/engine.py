@@ -477,9 +477,11 @@ class TrainEngine:
 
     # (N, K) -> workgroup tile of csrc/kvq_gemm2.hip for the shapes where it beats the tuned library at 8192 rows
     # (tools/gemm2_probe.py on MI355X, interleaved rounds; gpurun_out/g2_probe*.log); every other shape stays with hipBLASLt
-    # "p" = the persistent tile loop (KVQ_GEMM_PERSISTENT): wherever a CU owns two or more tiles (tools/gemm2_probe_persist.py at
-    # round 3: QKV 37.4 -> 32.5 us, FFN1 42.9 -> 38.8, all-layer cross-K/V 216 -> 203 with column bands; library 36.8 / 45.4 / 196).
-    # The LM head keeps the one-tile kernel (354.7 us with column bands; persistent 362; library 344): with it the step has no
+    # "p" = the persistent tile loop (KVQ_GEMM_PERSISTENT), for shapes where a CU owns two or more tiles.  When it was built it won
+    # 10-12 % on QKV / FFN1 (tools/gemm2_probe_persist.py); the start-up fix of the one-tile kernel took most of
+    # that back: whole-step A/B on one box at the end of round 3 (tools/ab_env.sh) 17.28 ms with every "p" below, 17.31 with the QKV
+    # projection on the one-tile kernel, 17.23 with FFN1 + GELU on the one-tile kernel (hence no "p" there), cross-K/V a tie.
+    # The LM head keeps the one-tile kernel (327 us with column bands; persistent 346; library 332): with it the step has no
     # vendor-library GEMM left.
     _OWN_FWD = {(768, 768): "128x192", (768, 3072): "128x192", (2304, 768): "128x192p", (18432, 768): "256x256p",
                 (30528, 768): "256x256"}                                                    # y = x . W^T + b        ("nt")
@@ -489,7 +491,7 @@ class TrainEngine:
     # per element (Phi and phi share the exponential) and packed f32 FMAs; measured on MI355X (tools/gemm2_probe.py epi):
     # FFN1 forward 57.7 us against 44.5 + 19.3 (GEMM + gelu kernel), FFN2 backward 65.6 against 45.3 + 29.8; in the step
     # 19.07 -> 18.58 ms (gpurun_out/ab5.log).  KVQ_OWN_GELU="" / KVQ_OWN_DGELU="" switch back to the separate kernels.
-    _OWN_GELU = {(3072, 768): "256x192p"}                                       # (h, gelu(h)) = x . W^T + b
+    _OWN_GELU = {(3072, 768): "256x192"}                                        # (h, gelu(h)) = x . W^T + b
     _OWN_DGELU = {(3072, 768): "256x192"}                                       # (gy . W) * gelu'(h) + bias-gradient partials
     _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "128x256"}      # gW = gy^T . x          ("tn"), own launch
     # (LM-head weight gradient: 128x256 329 us, 256x192 354, 256x256 373 in tools/gemm2_probe.py at round 3)
