@@ -648,6 +648,12 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / C::WN, wn = w % C::WN;
+    if constexpr (SINGLE) {
+        // every kernel argument the start-up needs in ONE batch of scalar loads (left to itself hipcc requests the pointers a
+        // few hundred instructions later, when they are first used: a second dependent trip to the scalar cache)
+        const Problem& q = P.p[0];
+        asm volatile("" ::"s"(q.A), "s"(q.B), "s"(q.C), "s"(q.bias), "s"(q.lda), "s"(q.ldb), "s"(q.ldc), "s"(q.K));
+    }
     const TileId ti = locate_tile<C, SINGLE>(P, blockIdx.x);
     const Problem& pr = P.p[SINGLE ? 0 : ti.pi];
     const int m0 = ti.m0, n0 = ti.n0;
