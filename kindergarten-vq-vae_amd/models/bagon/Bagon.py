@@ -167,8 +167,11 @@ class Bagon(nn.Module):
         self._decoder_cross_attn_make_trainable(self.cross_attn_make_trainable)
 
     def _set_mode_enc_head_dec_head_ft(self):
-        self._set_mode_dec_head_ft()
+        # Order as in the reference (models/bagon/Bagon.py:139-146): the label is assigned first and _set_mode_dec_head_ft() then
+        # overwrites it, so `model_mode` reads "dec-head-ft" in this mode too -- kept, a consumer of the attribute sees what the
+        # reference shows; the parameter sets are what the mode name says (tests/test_engine_gpu.py::test_freeze_modes_match_reference_counts)
         self.model_mode = "enc-dec-head-ft"
+        self._set_mode_dec_head_ft()
         self._module_make_trainable(self.encoder.encoder.layer[-1], True)
         if self.encoder.pooler is not None:
             self._module_make_trainable(self.encoder.pooler, True)
