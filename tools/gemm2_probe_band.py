@@ -37,9 +37,8 @@ def run(M, N, K, tile, bands):
     for d, nm in (("0", "tile"), ("2", "persist")):
         for bd in bands:
             def f(d=d, bd=bd):
-                os.environ["KVQ_GEMM_DIRECT"] = d
                 os.environ["KVQ_GEMM_BAND"] = str(bd)
-                return nnops.gemm(a, b, "nt", bias=bias, out=out, tile=tile)
+                return nnops.gemm(a, b, "nt", bias=bias, out=out, tile=tile + ("p" if d == "2" else ""))
             out.fill_(float("nan"))
             o = f()
             torch.cuda.synchronize()
@@ -56,7 +55,6 @@ def run(M, N, K, tile, bands):
         m = sorted(v)[len(v) // 2]
         print(f"    {k:22s} {m:7.1f} us {fl / m / 1e6:5.0f} TF", flush=True)
     os.environ["KVQ_GEMM_BAND"] = "0"
-    os.environ["KVQ_GEMM_DIRECT"] = "0"
 
 
 run(8192, 30528, 768, "256x256", [2, 4, -4, -6, -8, -15])

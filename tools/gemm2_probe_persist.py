@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One-tile-per-workgroup kernel vs the persistent tile loop (KVQ_GEMM_DIRECT=2) of csrc/kvq_gemm2.hip, NT layout, interleaved
-rounds in one process; results checked against torch.  usage: gemm2_probe_persist.py [rounds]"""
+"""One-tile-per-workgroup kernel vs the persistent tile loop (tile name + "p" = KVQ_GEMM_PERSISTENT) of csrc/kvq_gemm2.hip, NT
+layout, interleaved rounds in one process; results checked against torch.  usage: gemm2_probe_persist.py [rounds]"""
 import os
 import sys
 
@@ -35,12 +35,11 @@ def run(N, K, tiles, M=T):
     ref = torch.addmm(bias, a, b.t())
     fns, res = {"lib": lambda: torch.addmm(bias, a, b.t())}, {"lib": []}
     for t in tiles:
-        for d, nm in (("0", "tile"), ("2", "persist"), ("3", "persist-plain")):
+        for d, nm in (("0", "tile"), ("2", "persist")):
             out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
 
             def f(t=t, d=d, out=out):
-                os.environ["KVQ_GEMM_DIRECT"] = d
-                return nnops.gemm(a, b, "nt", bias=bias, out=out, tile=t)
+                return nnops.gemm(a, b, "nt", bias=bias, out=out, tile=t + ("p" if d == "2" else ""))
             out.fill_(float("nan"))
             o = f()
             torch.cuda.synchronize()

@@ -15,7 +15,6 @@ from kvq import _ffi  # noqa: E402
 _ffi.LIB_PATH = os.path.join(ROOT, "kindergarten-vq-vae_amd", "lib", "diag", "libkvq.so")
 from kvq import nnops  # noqa: E402
 
-os.environ["KVQ_GEMM_DIRECT"] = "2"
 M, N, K, tile = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 lib = _ffi.lib()
 lib.kvq_diag_set_buffer.argtypes = [ctypes.c_void_p]
@@ -28,10 +27,10 @@ bm, bn = (int(v) for v in tile.split("x"))
 ntiles = -(-M // bm) * -(-N // bn)
 buf = torch.zeros((ntiles, 16), dtype=torch.int64, device=dev)
 for _ in range(3):
-    nnops.gemm(a, b, "nt", bias=bias, out=out, tile=tile)
+    nnops.gemm(a, b, "nt", bias=bias, out=out, tile=tile + "p")
 torch.cuda.synchronize()
 assert lib.kvq_diag_set_buffer(buf.data_ptr()) == 0
-nnops.gemm(a, b, "nt", bias=bias, out=out, tile=tile)
+nnops.gemm(a, b, "nt", bias=bias, out=out, tile=tile + "p")
 torch.cuda.synchronize()
 lib.kvq_diag_set_buffer(None)
 s = buf.cpu().numpy().astype(np.int64)
