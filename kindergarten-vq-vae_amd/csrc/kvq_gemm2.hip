@@ -582,7 +582,7 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
 // 16-column blocks: afterwards an even-fk lane holds 8 consecutive columns of block ni0 and its odd partner 8 consecutive
 // columns of block ni0 + 1 -- one 16-byte store per lane, 16 rows x 64 contiguous bytes per wave-instruction, the other half of
 // each 128-byte line by the wave's next instruction.  No LDS, no barrier; in the one-tile-per-workgroup kernel it ties with the
-// LDS-transposed epilogue on every shape (tools/gemm2_probe_direct.py at round 3: 768^2 14.2 vs 14.3 us, FFN1 44.4 vs 44.4, LM
+// LDS-transposed epilogue on every shape (measured at round 3 with a probe build since removed: 768^2 14.2 vs 14.3 us, FFN1 44.4 vs 44.4, LM
 // head 362.8 vs 366.1) -- what it buys is that a persistent tile loop keeps its ring in flight across it.
 
 // ---- the k loop of one tile.  On entry the ring holds k-tiles 0 .. min(NS, nkt) - 1 of the tile (issued, not yet waited for)

@@ -206,9 +206,9 @@ def test_every_own_gemm_of_the_engine_step_against_f32_matmul_of_its_operands(mo
     out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
     assert np.isfinite(out["loss_recon"].item()) and not recorded
     print("own GEMM launches checked inside the engine step:", seen, "worst:", worst)
-    # 2 + 2 layers: every family ran, the persistent forward kernels included
+    # 2 + 2 layers: every family ran, the persistent forward kernel (the four QKV projections) included
     assert seen["nt"] >= 12 and seen["nn"] >= 14 and seen["tn"] >= 1 and seen["gelu"] == 4 and seen["dgelu"] == 4
-    assert seen["grouped"] >= 20 and seen["persistent"] >= 8
+    assert seen["grouped"] >= 20 and seen["persistent"] >= 4
 
 
 def test_engine_graph_step_at_bert_base_shapes_trains():
