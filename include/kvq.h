@@ -366,6 +366,9 @@ int kvq_adam_step_dev(float* p, const void* g, float* m, float* v, float* vmax, 
                       void* stream);
 int kvq_set_seed_offset(const void* step_state);
 int kvq_dropout(const void* x, int64_t n, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* stream);
+/* Zero 1..4 byte ranges (16-byte aligned pointers and sizes) in one launch: the word / position / token-type gradient tables of
+ * BertEmbeddings (modeling_bert.py:53-58) before kvq_embed_grad and the batched reductions add into them. */
+int kvq_zero_ranges(void* const* ptrs, const int64_t* bytes, int n, void* stream);
 
 
 /* Word-embedding gradient (autograd of the row gather of BertEmbeddings, modeling_bert.py:53-58):

@@ -2002,6 +2002,24 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     if (partials && p.pb_v) p.pb_v[(size_t)b * p.ldp_kv + col] = weighted_colsum(Xt, Wv + 64, r, h);
 }
 
+// Zero up to four byte ranges (16-byte aligned, multiples of 16 bytes) in ONE launch: the gradient tables of BertEmbeddings
+// (word / position / token-type) before the embedding-gradient kernels add into them -- three fill launches per table set before.
+struct ZeroRanges {
+    void* p[4];
+    long long n16[4];        // 16-byte units
+    int n;
+};
+__global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges z) {
+    const uint4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r < z.n) {
+            uint4* q = reinterpret_cast<uint4*>(z.p[r]);
+            for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < z.n16[r]; i += (long long)gridDim.x * 256) q[i] = zero;
+        }
+    }
+}
+
 }  // namespace kvq
 
 using namespace kvq;
@@ -2392,6 +2410,23 @@ int kvq_gumbel_backward(const void* logits, const float* y_soft, const void* g_y
 int kvq_set_seed_offset(const void* step_state) {
     g_seed_off = reinterpret_cast<const unsigned long long*>(step_state);
     return KVQ_OK;
+}
+
+int kvq_zero_ranges(void* const* ptrs, const int64_t* bytes, int n, void* stream) {
+    KVQ_REQUIRE(ptrs && bytes && n >= 1 && n <= 4, "kvq_zero_ranges: 1..4 ranges");
+    ZeroRanges z = {};
+    z.n = n;
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        KVQ_REQUIRE(ptrs[i] && bytes[i] > 0 && bytes[i] % 16 == 0 && ((uintptr_t)ptrs[i] & 15) == 0, "kvq_zero_ranges: range %d: 16-byte aligned pointer and size", i);
+        z.p[i] = ptrs[i];
+        z.n16[i] = bytes[i] / 16;
+        most = z.n16[i] > most ? z.n16[i] : most;
+    }
+    const long long want = (most + 255) / 256;
+    const unsigned blocks = (unsigned)(want > 4096 ? 4096 : want);
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z);
+    return check_launch("zero_ranges_kernel");
 }
 
 int kvq_dropout(const void* x, int64_t n, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* stream) {

@@ -745,6 +745,7 @@ class TrainEngine:
         ids, pre, mean, rstd, keep = saved
         B, S = ids.shape
         tr = fl.trainable
+        zeroed = False                                        # position / type tables already zeroed together with the word table
         # dropout(LayerNorm(x)): the mask applies to the incoming gradient, inside the LayerNorm backward kernel
         g_y, part = nnops.ln_dropout_bwd_partial(g, pre, mean, rstd, fl.w32(prefix + "ln.w"), keep[0] if keep else 0.0,
                                                  self._step_seed, keep[1] if keep else 0)
@@ -766,7 +767,13 @@ class TrainEngine:
                 # where the batch is built (prepare_batch: dsentences.token_cache / the trainer), not inside the replayed step
                 if self._sorted_ids is None:
                     self._sorted_ids = self.prepare_batch(ids)
-                if not tied_accumulate:
+                # the tables are zeroed by ONE launch (word unless it accumulates into the LM-head gradient, position, token type)
+                zero = [None if tied_accumulate else gw, fl.g(prefix + "pos") if tr[prefix + "pos"] else None,
+                        fl.g(prefix + "type") if tr[prefix + "type"] else None]
+                if all(t is None or (t.data_ptr() % 16 == 0 and (t.numel() * t.element_size()) % 16 == 0) for t in zero):
+                    nnops.zero_ranges(zero)
+                    zeroed = True
+                elif not tied_accumulate:
                     gw.zero_()
                 nnops.embed_grad(g_y, self._sorted_ids[1], self._sorted_ids[0], gw, accumulate=tied_accumulate)
             else:
@@ -783,12 +790,14 @@ class TrainEngine:
         Hh = g_pt.shape[1]
         if tr[prefix + "pos"]:
             gp = fl.g(prefix + "pos")
-            gp.zero_()
+            if not zeroed:
+                gp.zero_()
             part = nnops.colsum_partial(g_pt.view(B, S * Hh))
             self._defer(part, gp[:S], part.shape[0], S * Hh, S * Hh)
         if tr[prefix + "type"]:
             gt = fl.g(prefix + "type")
-            gt.zero_()
+            if not zeroed:
+                gt.zero_()
             part = nnops.colsum_partial(g_pt)
             self._defer(part, gt[0], part.shape[0], Hh, Hh)
 

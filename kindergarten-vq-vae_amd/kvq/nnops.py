@@ -241,6 +241,17 @@ def dropout(x, p_drop, seed, site, out=None):
     return o
 
 
+def zero_ranges(tensors):
+    """Zero up to four contiguous tensors (16-byte aligned, sizes multiples of 16 bytes) in one launch."""
+    import ctypes
+    ts = [t for t in tensors if t is not None]
+    if not ts:
+        return
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    sizes = (ctypes.c_int64 * len(ts))(*[t.numel() * t.element_size() for t in ts])
+    check(lib().kvq_zero_ranges(ptrs, sizes, len(ts), stream_ptr()), "kvq_zero_ranges")
+
+
 def embed_grad(g, perm, sorted_ids, gW, accumulate=False):
     """gW[id] (= | +=) sum of g[n] over the tokens with that id, in token order (deterministic, no atomics).
     perm / sorted_ids: stable sort of the flattened ids (sorted_ids, perm = torch.sort(ids.reshape(-1), stable=True))."""
