@@ -639,23 +639,12 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
     __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring is free (it becomes the epilogue tile)
 }
 
-template <class C, int EPI, bool SINGLE>
-__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    G2_STAMP(0);
-    G2_STAMP_VAL(1, __builtin_amdgcn_s_memrealtime());
-    G2_STAMP_VAL(2, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));
+// one tile of problem `pr`: ring prologue, k loop, epilogue
+template <class C, int EPI>
+__device__ __forceinline__ void gemm2_tile(const Problem& pr, const TileId& ti, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / C::WN, wn = w % C::WN;
-    if constexpr (SINGLE) {
-        // every kernel argument the start-up needs in ONE batch of scalar loads (left to itself hipcc requests the pointers a
-        // few hundred instructions later, when they are first used: a second dependent trip to the scalar cache)
-        const Problem& q = P.p[0];
-        asm volatile("" ::"s"(q.A), "s"(q.B), "s"(q.C), "s"(q.bias), "s"(q.lda), "s"(q.ldb), "s"(q.ldc), "s"(q.K));
-    }
-    const TileId ti = locate_tile<C, SINGLE>(P, blockIdx.x);
-    const Problem& pr = P.p[SINGLE ? 0 : ti.pi];
     const int m0 = ti.m0, n0 = ti.n0;
     const int nkt = pr.K / BK;
 
@@ -686,6 +675,49 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
     G2_STAMP(8);
     G2_STAMP_VAL(9, __builtin_amdgcn_s_memrealtime());
 #endif
+}
+
+// several problems in one grid (the grouped weight gradients): the problem of a tile is looked up in the argument struct
+template <class C, int EPI>
+__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    G2_STAMP(0);
+    G2_STAMP_VAL(1, __builtin_amdgcn_s_memrealtime());
+    G2_STAMP_VAL(2, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));
+    const TileId ti = locate_tile<C, false>(P, blockIdx.x);
+    gemm2_tile<C, EPI>(P.p[ti.pi], ti, smem);
+}
+
+// ONE problem (every launch of the step but the grouped weight gradients).  What the workgroup needs before its first DMA --
+// the tile walk's constants, the operand and bias pointers, the leading dimensions, K, M, N -- are the FIRST 14 DWORDS of the kernel
+// arguments, as scalars (four pairs of 16-bit numbers packed; a problem with a number above 65535 takes gemm2_kernel): with -amdgpu-kernarg-preload-count they arrive in SGPRs with the
+// wave, no s_load and no wait (14 is what the hardware preloads; a by-value struct cannot be preloaded at all).  Everything else
+// (C, bias, the epilogue's pointers) is read from `rest` when used.
+template <class C, int EPI>
+__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2s_kernel(int ntiles_band, int tiles_mn, unsigned mg_per_band, unsigned mg_full,
+                                                                          unsigned mg_rem, int K, const unsigned short* A, const unsigned short* B,
+                                                                          const unsigned short* bias, int ld_ab, int mn, Problem rest) {
+    const int ntiles = ntiles_band & 0xffff, band = ntiles_band >> 16;                  // (band is signed: arithmetic shift)
+    const int tiles_m = tiles_mn & 0xffff, tiles_n = (int)((unsigned)tiles_mn >> 16);
+    const int lda = ld_ab & 0xffff, ldb = (int)((unsigned)ld_ab >> 16), M = mn & 0xffff, N = (int)((unsigned)mn >> 16);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    G2_STAMP(0);
+    G2_STAMP_VAL(1, __builtin_amdgcn_s_memrealtime());
+    G2_STAMP_VAL(2, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));
+    Problem pr = rest;
+    pr.band = band; pr.tiles_m = tiles_m; pr.tiles_n = tiles_n; pr.mg_per_band = mg_per_band; pr.mg_full = mg_full; pr.mg_rem = mg_rem;
+    pr.K = K; pr.A = A; pr.B = B; pr.bias = bias; pr.lda = lda; pr.ldb = ldb; pr.M = M; pr.N = N; pr.tile0 = 0;
+    TileId ti;
+    {
+        int id = blockIdx.x;
+        const int q = ntiles >> 3, r = ntiles & 7, x = id & 7;               // XCD-aware numbering (see locate_tile)
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+        ti.pi = 0;
+        band_walk(pr, id, ti.tm, ti.tn);
+        ti.m0 = ti.tm * C::BM;
+        ti.n0 = ti.tn * C::BN;
+    }
+    gemm2_tile<C, EPI>(pr, ti, smem);
 }
 
 // (A persistent form -- gridDim.x = CUs workgroups walking the tiles, the next tile's ring issued before this tile's epilogue, the
@@ -1045,23 +1077,25 @@ template <bool AK, bool BKM> using Cfg128x192 = Cfg<128, 192, 2, 4, AK, BKM, 3>;
 template <bool AK, bool BKM> using Cfg256x256 = Cfg<256, 256, 2, 4, AK, BKM, 2>;     // 8 waves, 128 KiB
 template <bool AK, bool BKM> using Cfg128x192p = Cfg<128, 192, 4, 2, AK, BKM, 3>;    // persistent form: an even number of 16-column blocks per wave
 
-template <class C, int EPI, bool SINGLE>
-static int launch_cfg1(const Params& P, hipStream_t st) {
+template <class C, int EPI = EPI_NONE>
+static int launch_cfg(const Params& P, hipStream_t st) {
     static std::atomic<bool> attr_done{false};      // per instantiation; idempotent, so a race only repeats the call
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<C, EPI, SINGLE>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<C, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2s_kernel<C, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm2): %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm2_kernel<C, EPI, SINGLE>), dim3((unsigned)P.ntiles), dim3(C::THREADS), C::LDS, st, P);
-    return check_launch("gemm2_kernel");
-}
-template <class C, int EPI = EPI_NONE>
-static int launch_cfg(const Params& P, hipStream_t st) {
-    if constexpr (EPI == EPI_NONE) {
-        if (P.nprob > 1) return launch_cfg1<C, EPI, false>(P, st);      // (the epilogue variants are single-problem entry points)
+    const Problem& q = P.p[0];
+    const bool packs = P.nprob == 1 && P.ntiles < 65536 && q.M < 65536 && q.N < 65536 && q.lda < 65536 && q.ldb < 65536;
+    if (!packs) {
+        hipLaunchKernelGGL((gemm2_kernel<C, EPI>), dim3((unsigned)P.ntiles), dim3(C::THREADS), C::LDS, st, P);
+    } else {
+        hipLaunchKernelGGL((gemm2s_kernel<C, EPI>), dim3((unsigned)P.ntiles), dim3(C::THREADS), C::LDS, st, (int)((unsigned)P.ntiles | ((unsigned)q.band << 16)),
+                           (int)((unsigned)q.tiles_m | ((unsigned)q.tiles_n << 16)), q.mg_per_band, q.mg_full, q.mg_rem, q.K, q.A, q.B, q.bias,
+                           (int)((unsigned)q.lda | ((unsigned)q.ldb << 16)), (int)((unsigned)q.M | ((unsigned)q.N << 16)), q);
     }
-    return launch_cfg1<C, EPI, true>(P, st);
+    return check_launch("gemm2_kernel");
 }
 
 static int persistent_grid() {

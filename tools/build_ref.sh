@@ -6,7 +6,7 @@ root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 tmp="$(mktemp -d)"
 git -C "$root" archive "$commit" kindergarten-vq-vae_amd/csrc include | tar -x -C "$tmp"
 mkdir -p "$root/kindergarten-vq-vae_amd/lib/ref"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -I"$tmp/include" -I"$tmp/kindergarten-vq-vae_amd/csrc" -Wall -Wno-unused-function)
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno ${REF_EXTRA_FLAGS--mllvm -amdgpu-kernarg-preload-count=16} -I"$tmp/include" -I"$tmp/kindergarten-vq-vae_amd/csrc" -Wall -Wno-unused-function)
 objs=()
 for src in "$tmp"/kindergarten-vq-vae_amd/csrc/*.hip; do
   obj="$tmp/$(basename "${src%.hip}").o"
