@@ -96,3 +96,38 @@ def test_engine_fp8_trains_through_graph_replay():
     ids, mask = (t.cuda() for t in random_token_batch(64, 32, torch.Generator().manual_seed(5)))
     losses = [float(eng.train_step(ids, mask)["loss_recon"]) for _ in range(8)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0] and eng._graphs, losses
+
+
+def test_fp8_forward_with_the_nine_factor_quantiser_at_bert_base_widths():
+    """BASELINE.json configs[4] on one GPU: fp8 forward GEMMs AND nine codebooks over ragged slices of the 768 columns (86 / 85 wide),
+    2 layers, 2048 tokens, against the bf16 engine on the same weights and batch.  Stated tolerance: reconstruction loss within
+    2e-2 relative, VQ loss within 5e-2, nine tenths of the [B, S, 9] code indices equal, codebook-gradient cosine > 0.98; then
+    eight steps (eager, capture, replay) that lower the loss."""
+    from dsentences.synthetic import random_token_batch
+    from kvq.engine import TrainEngine
+    from models.shelgon3.MultiVectorQuantizer import MultiVectorQuantizer
+    from models.shelgon3.Shelgon import Shelgon
+    ids, mask = (t.cuda() for t in random_token_batch(64, 32, torch.Generator().manual_seed(6)))
+
+    def build():
+        torch.manual_seed(2)
+        mq = MultiVectorQuantizer(n_factors=9, n_e=512, e_dim=768, beta=0.25)
+        W = mq.embedding.weight.data
+        W.copy_(torch.randn_like(W) * (W != 0 if mq.ragged else 1))
+        return Shelgon("kvq-bert-base-2l", mq, "kvq-bert-base-2l", None, compute_dtype=torch.bfloat16).cuda().eval()
+
+    runs = {}
+    for fp8 in (False, True):
+        eng = TrainEngine(build(), lr=2e-4, fp8_forward=fp8)
+        assert eng.G == 9
+        out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+        runs[fp8] = (out["loss_recon"].item(), out["loss_vq"].item(), out["indices"].clone(), eng.gE.float().clone(), eng)
+    (l0, v0, i0, g0, _), (l1, v1, i1, g1, e8) = runs[False], runs[True]
+    assert i0.shape == (64, 32, 9)
+    np.testing.assert_allclose(l1, l0, rtol=2e-2)
+    np.testing.assert_allclose(v1, v0, rtol=5e-2)
+    assert (i0 == i1).float().mean().item() > 0.9
+    assert F.cosine_similarity(g1.reshape(-1), g0.reshape(-1), dim=0).item() > 0.98
+    e8.model.train()
+    losses = [float(e8.train_step(ids, mask)["loss_recon"]) for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] and e8._graphs, losses
