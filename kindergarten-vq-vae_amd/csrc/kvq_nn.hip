@@ -1312,6 +1312,18 @@ __device__ __forceinline__ unsigned long long attn_key_mask(const AttnParams& p,
     return kmask;
 }
 __device__ __forceinline__ unsigned long long attn_seed(const AttnParams& p) { return p.seed + (p.seed_off ? *p.seed_off : 0ull); }
+// The MFMA kernels split the mask in two so that no load sits behind a branch (hipcc waits vmcnt(0) at the join of one, i.e. for
+// every row load issued before it): the element load goes out FIRST and unconditionally -- without a mask it reads the head of q,
+// always there -- and the ballot happens after the dropout bits have been drawn, with the row loads still in flight.
+__device__ __forceinline__ int64_t attn_mask_element(const AttnParams& p, int b) {
+    const int l = threadIdx.x & 31;
+    const int64_t* mp = p.mask ? p.mask + ((size_t)b * p.Sk + (l < p.Sk ? l : p.Sk - 1)) : reinterpret_cast<const int64_t*>(p.q);
+    return *mp;
+}
+__device__ __forceinline__ unsigned long long attn_mask_ballot(const AttnParams& p, int64_t mv) {
+    const unsigned long long kb = __ballot(mv != 0);
+    return p.mask ? kb : ~0ull;
+}
 
 template <int LAY = 0>
 __device__ __forceinline__ void attn_keep16(const AttnParams& p, int bh, int i, int h, float (&keep)[16], const unsigned long long* seed_pre = nullptr) {
@@ -1859,11 +1871,21 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
     const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
     const bool kvalid = r < p.Sk, qvalid = r < p.Sq;
     const int rk = kvalid ? r : p.Sk - 1, rq = qvalid ? r : p.Sq - 1;
+    const int64_t mv = attn_mask_element(p, b);                        // the first load out: its wait leaves the row loads in flight
     uint4 kf[4], qf[4], vf[4];
     load_row_chunks(p.k, ((size_t)b * p.Sk + rk) * p.ldk + hd * AT_D, h, kvalid, kf);
     load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
     load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
-    const unsigned long long kmask = attn_key_mask(p, b), seed = attn_seed(p);       // in flight with the row loads
+    // the dropout bits need nothing that is being loaded: ~2300 cycles of Philox per wave (quarter-rate 32 x 32 multiplies) drawn
+    // while the rows travel -- every wave of the launch is in the same phase, so nothing else would use the VALU then
+    const unsigned long long seed = attn_seed(p);
+    float keep[16];
+    if (p.p_drop > 0.f) attn_keep16<1>(p, bh, r, h, keep, &seed);
+    else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) keep[v] = 1.0f;
+    }
+    const unsigned long long kmask = attn_mask_ballot(p, mv);
     f32x16 acc = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma32(kf[s], qf[s], acc);      // S^T[key][query]
@@ -1873,12 +1895,8 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
     for (int v = 0; v < 16; ++v) s[v] = acc[v];
     float lse;
     scores_to_probs<1>(p, b, r, h, qvalid, s, lse, &kmask);
-    if (p.p_drop > 0.f) {
-        float keep[16];
-        attn_keep16<1>(p, bh, r, h, keep, &seed);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) s[v] *= keep[v];
-    }
+    for (int v = 0; v < 16; ++v) s[v] *= keep[v];
     uint4 pf[2];
     acc_to_frags(s, pf);
     __syncthreads();
@@ -1903,12 +1921,20 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
     const bool kvalid = r < p.Sk, qvalid = r < p.Sq;
     const int rk = kvalid ? r : p.Sk - 1, rq = qvalid ? r : p.Sq - 1;
+    const int64_t mv = attn_mask_element(p, b);                        // (see attn_fwd_mfma_kernel)
     uint4 kf[4], qf[4], vf[4], gf[4];
     load_row_chunks(p.k, ((size_t)b * p.Sk + rk) * p.ldk + hd * AT_D, h, kvalid, kf);
     load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
     load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
     load_row_chunks(p.g_out, ((size_t)b * p.Sq + rq) * p.ldo + hd * AT_D, h, qvalid, gf);
-    const unsigned long long kmask = attn_key_mask(p, b), seed = attn_seed(p);       // in flight with the row loads
+    const unsigned long long seed = attn_seed(p);
+    float keep[16];
+    if (p.p_drop > 0.f) attn_keep16<1>(p, bh, r, h, keep, &seed);      // drawn while the rows travel
+    else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) keep[v] = 1.0f;
+    }
+    const unsigned long long kmask = attn_mask_ballot(p, mv);
     f32x16 accS = zero16(), accP = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) accS = mfma32(kf[s], qf[s], accS);     // S^T[key][query]
@@ -1920,12 +1946,6 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     for (int v = 0; v < 16; ++v) { s[v] = accS[v]; dp[v] = accP[v]; }
     float lse;
     scores_to_probs<1>(p, b, r, h, qvalid, s, lse, &kmask);
-    float keep[16];
-    if (p.p_drop > 0.f) attn_keep16<1>(p, bh, r, h, keep, &seed);
-    else {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) keep[v] = 1.0f;
-    }
     float delta = 0.f;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
