@@ -371,6 +371,21 @@ int kvq_dropout(const void* x, int64_t n, float p_drop, uint64_t seed, uint32_t 
 int kvq_zero_ranges(void* const* ptrs, const int64_t* bytes, int n, void* stream);
 
 
+/* ---- the consumer of the code indices: word x code counts ------------------------------------------------------------------
+ * Replaces the per-token Python walk of analyses/unsupervised_vq_disentanglement/unsupervised_vq_disentanglement.py:166-200
+ * (`vq_words_distrib[code].append(word)`, `seen_v_is.add(code)` for every token of every word :181-183;
+ *  `words_of_interest_vq_distrib[word].append(v_is[0])` for a word's first token :192-199); the result files (:208-235) only use
+ * counts and sets of those lists, i.e. projections of
+ *     counts_all  [G][W][K] (uint32) += 1 for every token n with a word,      cell (g, slot(n), idx[n][g])
+ *     counts_first[G][W][K] (uint32) += 1 for the FIRST token of every word,  same cell
+ * slot_first [N] int32: -1 = the position belongs to no word (padding), else (slot << 1) | (1 if the word's first token);
+ * idx [N][G] int64 = min_encoding_indices as the quantisers return them.  The tables ACCUMULATE (zero them before the first batch).
+ * Positions with slot >= W or an index outside [0, K) are skipped and counted in *n_bad (optional).  Exact integer arithmetic;
+ * G * W * K < 2^31. */
+int kvq_code_census(const int32_t* slot_first, const int64_t* idx, int64_t N, int G, int K, int W, uint32_t* counts_all,
+                    uint32_t* counts_first, uint32_t* n_bad, void* stream);
+
+
 /* Word-embedding gradient (autograd of the row gather of BertEmbeddings, modeling_bert.py:53-58):
  *     gW[id][:] (= | +=) sum over the tokens n with ids[n] == id of g[n][:],   tokens added in increasing n  (deterministic)
  * The caller passes the tokens sorted by id: sorted_ids[s] ascending and perm[s] = the token at sorted position s (a STABLE

@@ -108,6 +108,7 @@ SIGNATURES = {
     "kvq_embed_grad": (_int, [_vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _int, _int, _vp, _sz, _vp]),
     "kvq_dropout": (_int, [_vp, _i64, _f32, C.c_uint64, C.c_uint32, _int, _vp, _vp]),
     "kvq_zero_ranges": (_int, [C.POINTER(_vp), C.POINTER(_i64), _int, _vp]),
+    "kvq_code_census": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -1001,12 +1001,13 @@ class TrainEngine:
     # one training step
     # ------------------------------------------------------------------------------------------------------------
     def forward_backward(self, input_ids, attention_mask, training=True, compute_grads=True, dec_ids=None, dec_mask=None,
-                         want_logits=False, quantizer_training=None, fuse_optimizer=False):
+                         want_logits=False, quantizer_training=None, fuse_optimizer=False, stop_after_quantizer=False):
         """Forward (+ backward when compute_grads).  Returns dict(loss_recon, loss_vq, perplexity, acc, recon_ids, indices
         [, logits]).  dec_ids / dec_mask: the decoder's own input (Bagon.forward takes one; default = the encoder's).
         fuse_optimizer (train_step only; optimizer_step() MUST follow): parameters are updated while backward still runs."""
         self._fuse_opt = bool(fuse_optimizer) and compute_grads and self._early_adam and not self._dp
         self._adam_hi, self._adam_forked = self.flat.n, False
+        self._stop_after_quantizer = bool(stop_after_quantizer) and not compute_grads
         S = max(input_ids.shape[1], dec_ids.shape[1] if dec_ids is not None else 0)
         if S > 32:
             raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
@@ -1041,6 +1042,18 @@ class TrainEngine:
             self._E_version = None             # an evaluation forward never trusts a cached pack (a 3-us kernel; see _codebook_stamp)
         return self.forward_backward(enc_ids, enc_mask, training=training, compute_grads=False, dec_ids=dec_ids, dec_mask=dec_mask,
                                      want_logits=True, quantizer_training=quantizer_training)
+
+    def code_indices(self, enc_ids, enc_mask, quantizer_training=False):
+        """Encoder + quantiser only: dict(indices, perplexity, loss_vq_raw).  What a consumer of the codes needs -- the reference's
+        analysis (analyses/unsupervised_vq_disentanglement/unsupervised_vq_disentanglement.py:164) runs the whole model.forward
+        and drops everything but min_encoding_indices; the decoder and the LM head are 60 % of a forward."""
+        if not self.has_vq:
+            raise KvqError("TrainEngine.code_indices: the model has no quantiser")
+        self.refresh_if_params_changed()
+        if getattr(self, "_epack", None) is not None:
+            self._E_version = None
+        return self.forward_backward(enc_ids, enc_mask, training=False, compute_grads=False, quantizer_training=quantizer_training,
+                                     stop_after_quantizer=True)
 
     def _forward_backward(self, input_ids, attention_mask, training, compute_grads, dec_ids=None, dec_mask=None, want_logits=False):
         m = self.model
@@ -1082,6 +1095,8 @@ class TrainEngine:
             idx, indices = ind, ind.view(B, S)                               # GumbelQuantizer.py:76 returns [B, S]
         else:
             idx, loss_vq, perplexity, enc_out, indices = None, None, None, z, None
+        if getattr(self, "_stop_after_quantizer", False):
+            return dict(indices=indices, perplexity=perplexity, loss_vq_raw=loss_vq)
 
         y, demb_saved = self._emb_fwd("dec.emb.", dcfg, d_ids, training, word_rows=None)
         dec_saved = []

@@ -65,6 +65,15 @@ class Shelgon(Bagon):
         logits = self.decode(z_q, input_ids, attention_mask)                       # Shelgon.py:71
         return vq_loss, perplexity, indices, logits
 
+    def code_indices(self, input_ids, attention_mask, device=None):
+        """min_encoding_indices of a batch without the decoder: what the index consumers use of forward()
+        (analyses/unsupervised_vq_disentanglement/unsupervised_vq_disentanglement.py:164 keeps only that element)."""
+        if self._engine_forward_ok(input_ids):
+            from kvq.engine import engine_of
+            return engine_of(self).code_indices(input_ids, attention_mask)["indices"]
+        with torch.no_grad():
+            return self._quantize(self.encode(input_ids, attention_mask), device)[3]
+
     def forward_loss(self, input_ids, attention_mask):
         """Fused step body: (vq_loss, perplexity, indices, loss_recon, acc_per_batch, recon_ids)."""
         embeds = self.encode(input_ids, attention_mask)
