@@ -69,6 +69,13 @@ def test_bagon_main_end_to_end(tmp_path):
     assert conf["model_mode"] == "dec-head-ft" and conf["n_params"]["encoder"]["n_trainable_params"] == 0
     logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
     assert any("test/loss_recon" in l for l in logs)
+    # common/test_checkpoint_validity.py of the reference: load that checkpoint into a fresh Bagon and reconstruct the probe sentences
+    env = dict(os.environ, PYTHONPATH=PKG, KVQ_CKPT_PATH=repr(run + "/bagon_ckpt_loss_recon_val_best.pth"),
+               KVQ_ENCODER_MODEL_NAME="'kvq-bert-tiny'", KVQ_DECODER_MODEL_NAME="'kvq-bert-tiny'")
+    r = subprocess.run([sys.executable, os.path.join(PKG, "common/test_checkpoint_validity.py")], env=env, cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "'he accepted the payment' -> " in r.stdout and "logits (3, 6, 2048)" in r.stdout and "finite: True" in r.stdout
 
 
 def test_codebook_init_script_feeds_shelgon_main(tmp_path):
