@@ -189,10 +189,10 @@ def _build_base():
     return model.eval()
 
 
-def _data_base():
+def _data_base(world=2):
     sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
     from dsentences.synthetic import random_token_batch
-    ids, mask = random_token_batch(128, 32, torch.Generator().manual_seed(11))
+    ids, mask = random_token_batch(64 * world, 32, torch.Generator().manual_seed(11))        # 64 sentences = 2048 tokens per rank
     return ids.cuda(), mask.cuda()
 
 
@@ -218,7 +218,7 @@ def _worker_base(rank, world, port, ref_path, out):
     from kvq.engine import TrainEngine
     torch.cuda.set_device(0)
     ddp.init_distributed("gloo")
-    ids, mask = _data_base()
+    ids, mask = _data_base(world)
     half = slice(rank * 64, rank * 64 + 64)
     ref = torch.load(ref_path, map_location="cuda")
     report = {}
@@ -227,7 +227,7 @@ def _worker_base(rank, world, port, ref_path, out):
         ddp.broadcast_parameters(model)
         eng = TrainEngine(model, lr=BASE_LR, bucket_mib=4)
         eng.use_graph = use_graph
-        assert eng.world == 2 and eng._dp and eng._own_wgrad and eng._cakv_batched
+        assert eng.world == world and eng._dp and eng._own_wgrad and eng._cakv_batched
         held, sent = [0], [0]
         flush, reduce_ = eng._flush_wgrads, eng._all_reduce_avg
 
@@ -267,7 +267,10 @@ def _worker_base(rank, world, port, ref_path, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_bf16_bert_base_shapes_equal_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_bf16_bert_base_shapes_equal_single_process(tmp_path, world):
+    """world ranks x 2048 tokens against ONE process on the concatenated batch (4 ranks + this process = 5 users of the card,
+    inside the box's limit of 6)."""
     sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
     from kvq.engine import TrainEngine
     # oracle: one process, the concatenated batch (equal token counts per half: the mean of the rank means is the global mean)
@@ -275,7 +278,7 @@ def test_two_ranks_bf16_bert_base_shapes_equal_single_process(tmp_path):
     eng = TrainEngine(model, lr=BASE_LR)
     eng.use_graph = False
     assert not eng._dp
-    ids, mask = _data_base()
+    ids, mask = _data_base(world)
     ref, ref_loss = {}, {}
     for step in range(1, BASE_STEPS + 1):
         _poison(eng)
@@ -289,7 +292,7 @@ def test_two_ranks_bf16_bert_base_shapes_equal_single_process(tmp_path):
     del eng, model, ref
     torch.cuda.empty_cache()
     out = str(tmp_path / "dp_base.pt")
-    mp.spawn(_worker_base, args=(2, _free_port(), ref_path, out), nprocs=2, join=True)
+    mp.spawn(_worker_base, args=(world, _free_port(), ref_path, out), nprocs=world, join=True)
     rep = torch.load(out)
     # the code under test really ran: the weight-gradient queue was held across layers, and the buffer left in >= 6 chunks
     assert rep["eager_held"] >= 2 * BASE_STEPS and rep["graph_held"] >= 2, rep["eager_held"]
@@ -304,7 +307,7 @@ def test_two_ranks_bf16_bert_base_shapes_equal_single_process(tmp_path):
         worst[(tag, step)] = max(worst.get((tag, step), (0.0, "")), (err, name))
         # bf16 gradients: each rank rounds its gradient to bf16 (2^-9) before the average, the one-process run rounds once
         assert err < 1.5e-2, f"{tag} step {step}: {name}: relative L2 difference {err:.3g} to the one-process gradient"
-    print("two ranks (bf16, bert-base widths) vs one process, worst relative L2 per run:", worst)
+    print(f"{world} ranks (bf16, bert-base widths) vs one process, worst relative L2 per run:", worst)
     for tag in ("eager", "graph"):
         for step in BASE_CHECK:
             assert abs(rep[(tag, step, "loss")] - ref_loss[step]) < 0.5, (tag, step)     # rank 0 sees its half only: same scale
