@@ -284,6 +284,7 @@ class TrainEngine:
         self._step_seed = (self.seed * 1000003) & 0x7FFFFFFFFFFFFFF      # + step count on the device
         self._graphs, self._eager_seen, self._cap, self._prepared = {}, {}, None, None
         self._own_fwd = os.environ.get("KVQ_OWN_GEMM", "1") != "0"
+        self._gumbel_own = 0                  # products of the Gumbel mode that ran on the own GEMM (tests read it)
         for attr, var in (("_OWN_FWD", "KVQ_OWN_FWD"), ("_OWN_DGRAD", "KVQ_OWN_DGRAD"), ("_OWN_GELU", "KVQ_OWN_GELU"),
                           ("_OWN_DGELU", "KVQ_OWN_DGELU"), ("_OWN_WGRAD_SINGLE", "KVQ_OWN_WGRAD_SINGLE")):
             if var in os.environ:       # "NxK:tile;NxK:tile" replaces the table (A/B runs on the GPU box); "" = all library
@@ -1308,12 +1309,27 @@ class TrainEngine:
         self._repack_codebook()
 
     # ---- GumbelQuantizer (models/shelgon3/GumbelQuantizer.py:43-83): 1x1 conv = GEMM, row kernel, codebook GEMM ----------------
+    def _mm(self, a, b, layout, bias=None):
+        """op(a) . op(b) (+ bias) for the six products of the Gumbel mode.  bf16 at step sizes -> csrc/kvq_gemm2.hip (its tiles want
+        the contraction in multiples of 64 and M, N, leading dimensions in multiples of 8, which n_embed = 512 codes meets and the
+        reference analysis' 9 codes do not); anything else -> torch (hipBLASLt).  layout as nnops.gemm: "nt" | "nn" | "tn"."""
+        M, N, K = nnops._gemm_dims(a, b, layout)
+        own = self._own_fwd and self.dtype == torch.bfloat16 and a.dtype == b.dtype == torch.bfloat16 and a.shape[0] >= 2048 \
+            and K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and a.stride(1) == 1 and b.stride(1) == 1 \
+            and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+        if own:
+            self._gumbel_own += 1
+            return nnops.gemm(a, b, layout, bias=bias)
+        A = a.t() if layout == "tn" else a
+        Bm = b.t() if layout == "nt" else b
+        return torch.addmm(bias, A, Bm) if bias is not None else A @ Bm
+
     def _gumbel_forward(self, z, training):
         gq = self.model.vector_quantizer
         N, H = z.shape
         K, dt = gq.n_embed, self.dtype
         Wp = gq.proj.weight.squeeze(-1).to(dt)                                        # [K, H]
-        logits = torch.addmm(gq.proj.bias.to(dt), z, Wp.t())
+        logits = self._mm(z, Wp, "nt", bias=gq.proj.bias.to(dt))
         hard = bool(gq.straight_through) if training else True                       # :54
         y = torch.empty_like(logits)
         y_soft = torch.empty((N, K), dtype=torch.float32, device=self.dev)
@@ -1326,7 +1342,7 @@ class TrainEngine:
               "kvq_gumbel_forward")
         diff = kl_row.mean() * float(gq.kld_scale)                                    # :73
         emb = gq.embed.weight.to(dt)
-        z_q = y @ emb                                                                 # :66 einsum, already [N, D]
+        z_q = self._mm(y, emb, "nn")                                                  # :66 einsum, already [N, D]
         used = torch.zeros(K, dtype=torch.float32, device=self.dev).scatter_add_(0, ind, self._ones.expand(N))
         perplexity = (used > 0).sum().float()                                         # codes in use (Shelgon.py:63)
         return z_q, diff, perplexity, ind, (z, logits, y, y_soft, Wp, emb)
@@ -1335,15 +1351,15 @@ class TrainEngine:
         gq = self.model.vector_quantizer
         z, logits, y, y_soft, Wp, emb = saved
         N, K = logits.shape
-        g_y = g_zq @ emb.t()
-        self.g_emb.copy_(y.t() @ g_zq)
+        g_y = self._mm(g_zq, emb, "nt")
+        self.g_emb.copy_(self._mm(y, g_zq, "tn"))
         gd = self._ones.reshape(1) * self.w_vq
         g_logits = torch.empty_like(logits)
         check(lib().kvq_gumbel_backward(logits.data_ptr(), y_soft.data_ptr(), g_y.data_ptr(), gd.data_ptr(), N, K, float(gq.temperature),
                                         float(gq.kld_scale), self.io, g_logits.data_ptr(), stream_ptr()), "kvq_gumbel_backward")
-        self.g_pw.copy_((g_logits.t() @ z).unsqueeze(-1))
+        self.g_pw.copy_(self._mm(g_logits, z, "tn").unsqueeze(-1))
         self.g_pb.copy_(g_logits.float().sum(0))
-        return g_logits @ Wp
+        return self._mm(g_logits, Wp, "nn")
 
     def _adam_ranges(self, lo, hi):
         fl = self.flat
