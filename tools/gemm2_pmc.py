@@ -41,7 +41,7 @@ def both(label, layout, M, N, K, tile):
 
 
 # tiles as the engine's tables select them at round 3 ("p" = the persistent tile loop)
-for n, k, t in [(768, 768, "128x192"), (2304, 768, "128x192p"), (3072, 768, "256x192p"), (768, 3072, "128x192"), (18432, 768, "256x256p"),
+for n, k, t in [(768, 768, "128x192"), (2304, 768, "128x192p"), (3072, 768, "256x192"), (768, 3072, "128x192"), (18432, 768, "256x256p"),
                 (30528, 768, "256x256")]:
     both("fwd", "nt", T, n, k, t)
 for n, k, t in [(768, 768, "128x192"), (768, 2304, "128x192"), (768, 3072, "128x192"), (3072, 768, "256x192"), (768, 18432, "128x192"),
@@ -61,7 +61,7 @@ def own_only(label, who, fn, flops, alg_bytes, layout, M, N, K):
 
 # FFN1 forward with the activation in the epilogue (two outputs), FFN2 input gradient with GELU' and the bias partials
 x, w1, b1 = rnd(T, 768), rnd(3072, 768), rnd(3072)
-own_only("fwd+gelu", "own fused 256x192p", lambda: nnops.gemm_gelu(x, w1, b1, tile="256x192p"), 2.0 * T * 3072 * 768,
+own_only("fwd+gelu", "own fused 256x192", lambda: nnops.gemm_gelu(x, w1, b1, tile="256x192"), 2.0 * T * 3072 * 768,
          2 * (T * 768 + 3072 * 768 + 2 * T * 3072), "nt", T, 3072, 768)
 gf, w2, h = rnd(T, 768), rnd(768, 3072), rnd(T, 3072)
 own_only("dgrad*gelu'", "own fused 256x192", lambda: nnops.gemm_dgelu(gf, w2, h, tile="256x192"), 2.0 * T * 3072 * 768,

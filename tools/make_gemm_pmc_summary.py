@@ -28,7 +28,7 @@ def groups(pass_name):
             cur = []
             out.append(cur)
             continue
-        if cur is not None and ("gemm2_kernel" in e["name"] or "gemm3_kernel" in e["name"] or "Cijk" in e["name"]):
+        if cur is not None and ("gemm2_kernel" in e["name"] or "gemm2s_kernel" in e["name"] or "gemm3_kernel" in e["name"] or "Cijk" in e["name"]):
             cur.append(e)
     out = out[len(out) - len(plan):]          # the marker tensor's own creation is a fill kernel too
     assert len(out) == len(plan), (len(out), len(plan))
@@ -57,7 +57,7 @@ lines = [f"# {tag}: GEMM counters per shape of the training step (1x MI355X, roc
 for i, p in enumerate(plan):
     if not p["who"]:
         continue
-    fam = ("gemm2_kernel", "gemm3_kernel") if p["who"].startswith("own") else ("Cijk",)       # (the other flavour's warm-up launch sits in this group too)
+    fam = ("gemm2_kernel", "gemm2s_kernel", "gemm3_kernel") if p["who"].startswith("own") else ("Cijk",)       # (the other flavour's warm-up launch sits in this group too)
     sq, fe, wr, gr = ([e for e in G[k][i] if any(f in e["name"] for f in fam)] for k in ("sq", "fetch", "write", "grbm"))
     if not sq:
         continue
