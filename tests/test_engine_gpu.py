@@ -120,6 +120,21 @@ def test_engine_training_reduces_loss_with_dropout():
     assert "vector_quantizer.embedding.weight" in state and "encoder.embeddings.word_embeddings.weight" in state
 
 
+def test_forward_only_engine_allocates_no_optimizer_state():
+    """The engine behind a no-autograd Shelgon.forward (engine_of(model)) holds master + shadow weights only; the gradient and
+    Adam-moment buffers appear with the first training step."""
+    from kvq.engine import engine_of
+    model = _build(torch.bfloat16).eval()
+    ids, mask = _batch()
+    with torch.no_grad():
+        model.forward(ids, mask, ids.device, False)
+    eng = engine_of(model, create=False)
+    assert eng is not None and not eng.flat.optimizer_state_allocated()
+    model.train()
+    eng.train_step(ids, mask)
+    assert eng.flat.optimizer_state_allocated() and eng.flat.m.abs().sum().item() > 0
+
+
 def test_engine_rejects_long_sequences():
     from kvq._ffi import KvqError
     from kvq.engine import TrainEngine
