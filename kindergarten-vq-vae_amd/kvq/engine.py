@@ -52,6 +52,44 @@ def engine_of(model, create=True):
     return eng
 
 
+class _EngineForward(torch.autograd.Function):
+    """model.forward with autograd ON, on the engine's kernels: forward = TrainEngine.forward_backward(defer_backward=True),
+    backward = TrainEngine.backward_from(d logits, d loss_vq).  The model's parameters are the function's inputs, so autograd
+    accumulates into their .grad as for any other op.  (The ATen restatement kvq/bert.py stays the default when torch must
+    differentiate: it is the independent checker of this schedule.  Opt in per model: model.autograd_backend = "engine".)"""
+
+    @staticmethod
+    def forward(ctx, eng, ids, mask, training, q_training, *params):
+        out = eng.forward_backward(ids, mask, training=training, compute_grads=False, want_logits=True, quantizer_training=q_training,
+                                   defer_backward=True)
+        ctx.eng, ctx.resume, ctx.params = eng, out["_resume"], params
+        logits = out["logits"]
+        ctx.logits_shape = tuple(logits.shape)
+        loss_vq = out["loss_vq_raw"] if out.get("loss_vq_raw") is not None else torch.zeros((), device=logits.device)
+        perp = out["perplexity"] if out.get("perplexity") is not None else torch.zeros((), device=logits.device)
+        idx = out["indices"] if out.get("indices") is not None else torch.zeros(0, dtype=torch.int64, device=logits.device)
+        loss_vq, perp = loss_vq.clone(), perp.clone()          # (views of one two-element result buffer otherwise)
+        ctx.mark_non_differentiable(perp, idx)
+        return logits, loss_vq, perp, idx
+
+    @staticmethod
+    def backward(ctx, g_logits, g_loss_vq, _g_perp, _g_idx):
+        eng = ctx.eng
+        if g_logits is None:                                   # a loss of the quantiser term alone
+            g_logits = torch.zeros(ctx.logits_shape, device=eng.dev, dtype=eng.dtype)
+        eng.backward_from(ctx.resume, g_logits.to(eng.dtype), g_loss_vq)
+        by_p = eng.grads_by_parameter()
+        return (None, None, None, None, None) + tuple(by_p.get(p) if p.requires_grad else None for p in ctx.params)
+
+
+def engine_autograd_forward(model, ids, mask, q_training=None):
+    """(logits [B, S, V], loss_vq (unweighted), perplexity, indices) of `model` with an autograd edge to every parameter."""
+    eng = engine_of(model)
+    eng.refresh_if_params_changed()
+    params = tuple(p for p in model.parameters())
+    return _EngineForward.apply(eng, ids, mask, model.training, q_training, *params)
+
+
 def _round_up(x, a):
     return (x + a - 1) // a * a
 
@@ -472,6 +510,7 @@ class TrainEngine:
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         self._g_recon = torch.full((), self.w_recon, dtype=torch.float32, device=dev)     # d total / d loss term: constants of the run
         self._g_vq = torch.full((), self.w_vq, dtype=torch.float32, device=dev)
+        self._g_vq_ext = None                  # backward_from(): the caller's d L / d loss_vq_raw instead of the run's constant
         _load_gemm_tuning()
 
     # ------------------------------------------------------------------------------------------------------------
@@ -1029,18 +1068,23 @@ class TrainEngine:
     # one training step
     # ------------------------------------------------------------------------------------------------------------
     def forward_backward(self, input_ids, attention_mask, training=True, compute_grads=True, dec_ids=None, dec_mask=None,
-                         want_logits=False, quantizer_training=None, fuse_optimizer=False, stop_after_quantizer=False):
+                         want_logits=False, quantizer_training=None, fuse_optimizer=False, stop_after_quantizer=False,
+                         defer_backward=False):
         """Forward (+ backward when compute_grads).  Returns dict(loss_recon, loss_vq, perplexity, acc, recon_ids, indices
         [, logits]).  dec_ids / dec_mask: the decoder's own input (Bagon.forward takes one; default = the encoder's).
-        fuse_optimizer (train_step only; optimizer_step() MUST follow): parameters are updated while backward still runs."""
+        fuse_optimizer (train_step only; optimizer_step() MUST follow): parameters are updated while backward still runs.
+        defer_backward (with compute_grads=False): the forward's activations stay alive and out["_resume"] can be handed to
+        backward_from() once the gradient of the returned logits is known (kvq.engine.engine_autograd_forward)."""
         self._fuse_opt = bool(fuse_optimizer) and compute_grads and self._early_adam and not self._dp
         self._adam_hi, self._adam_forked = self.flat.n, False
         self._stop_after_quantizer = bool(stop_after_quantizer) and not compute_grads
         S = max(input_ids.shape[1], dec_ids.shape[1] if dec_ids is not None else 0)
         if S > 32:
             raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
-        if compute_grads and dec_ids is not None:
+        if (compute_grads or defer_backward) and dec_ids is not None:
             raise KvqError("TrainEngine: the backward schedule covers the autoencoding step (decoder input = encoder input)")
+        if defer_backward and (compute_grads or self._cap is not None or self._dp):
+            raise KvqError("TrainEngine: defer_backward is a single-process, eager, forward-first call")
         self._site_ctr = 0
         self._red_items, self._red_keep = [], []
         self._wg_items, self._wg_keep = [], []
@@ -1052,7 +1096,11 @@ class TrainEngine:
             with torch.no_grad():            # the schedule IS the backward pass: no autograd graph over the few torch ops in it
                 if self.fp8:
                     self._a8_site = 0
-                out = self._forward_backward(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits)
+                out = self._forward_backward(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits,
+                                             defer=bool(defer_backward))
+                if defer_backward:
+                    out["_resume"] = dict(gen=out.pop("_gen"), sorted_ids=self._sorted_ids, step=self._step_host,
+                                          versions=self._versions())
                 if self.fp8 and compute_grads:
                     # the next TRAINING step's activation scales from this step's amax (4x headroom).  A forward-only call
                     # (evaluation, Shelgon.forward) uses the scales as they are and leaves them alone: an eval batch must not
@@ -1083,7 +1131,58 @@ class TrainEngine:
         return self.forward_backward(enc_ids, enc_mask, training=False, compute_grads=False, quantizer_training=quantizer_training,
                                      stop_after_quantizer=True)
 
-    def _forward_backward(self, input_ids, attention_mask, training, compute_grads, dec_ids=None, dec_mask=None, want_logits=False):
+    def _forward_backward(self, input_ids, attention_mask, training, compute_grads, dec_ids=None, dec_mask=None, want_logits=False,
+                          defer=False):
+        gen = self._fb_gen(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits, defer)
+        try:
+            out = next(gen)                 # only a deferred call yields: forward done, the generator holds the activations
+        except StopIteration as done:
+            return done.value
+        out["_gen"] = gen
+        return out
+
+    def backward_from(self, resume, g_logits, g_loss_vq=None):
+        """The backward half of a forward_backward(..., defer_backward=True) call, seeded with d L / d logits ([B, S, V], the
+        logits' dtype) and d L / d loss_vq_raw (scalar tensor or None = 0) instead of this engine's own loss: gradients land in
+        the flat buffer exactly as in a training step (grads_by_parameter() hands them out)."""
+        if resume.get("done"):
+            raise KvqError("TrainEngine.backward_from: this forward's activations were already consumed")
+        if resume["step"] != self._step_host or resume["versions"] != self._versions():
+            raise KvqError("TrainEngine.backward_from: parameters changed since the forward (an optimiser step or an in-place write)")
+        resume["done"] = True
+        self._red_items, self._red_keep = [], []
+        self._wg_items, self._wg_keep = [], []
+        self._sorted_ids = resume["sorted_ids"]
+        self._fuse_opt = False
+        self._g_vq_ext = (g_loss_vq.detach().to(torch.float32).reshape(()) if g_loss_vq is not None
+                          else torch.zeros((), dtype=torch.float32, device=self.dev)) if self.has_vq else None
+        nnops.set_seed_offset(self._state)          # the step count has not moved: backward regenerates the forward's dropout masks
+        try:
+            with torch.no_grad():
+                try:
+                    resume["gen"].send(g_logits.detach())
+                except StopIteration:
+                    pass
+                else:
+                    raise KvqError("TrainEngine.backward_from: the schedule did not finish")
+        finally:
+            nnops.set_seed_offset(None)
+            self._g_vq_ext = None
+
+    def grads_by_parameter(self):
+        """{nn.Parameter: float32 gradient} of the last backward, for every trainable parameter of the model (what autograd would
+        have put into .grad): views of the flat bf16 / f32 gradient buffer converted to the parameter's dtype."""
+        out = {}
+        for name, p in self.param_of.items():
+            if p.requires_grad:
+                g = self.flat.g(name)
+                out[p] = torch.empty_like(p).copy_(g.reshape(p.shape))           # a copy: the flat buffer is rewritten by the next backward
+        for a in self.aux:
+            if a["p"].requires_grad:
+                out[a["p"]] = torch.empty_like(a["p"]).copy_(a["g"].reshape(a["p"].shape))
+        return out
+
+    def _fb_gen(self, input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits, defer):
         m = self.model
         fl, H = self.flat, self.H
         B, S = input_ids.shape
@@ -1167,15 +1266,25 @@ class TrainEngine:
         if want_logits:
             out["logits"] = logits[:, :self.V].reshape(B, Sd, self.V)
             out["loss_vq_raw"] = loss_vq                          # without the trainer's loss weight
+        g_ext = None
         if not compute_grads:
-            return out
+            if not defer:
+                return out
+            g_ext = yield out               # suspended here until backward_from() sends d L / d logits
 
         # ---------------- backward ----------------
         if self._fuse_opt:      # lr / bias corrections of the step about to be applied; the step COUNT (dropout seed offset) stays
             nnops.step_state_advance(self._state, self.lr, self.gamma, self.milestones, self.betas[0], self.betas[1], phase="prepare")
         tr = fl.trainable
         g_scale = self._g_recon
-        if tr["head.bias"] and self.Vp % 8 == 0:
+        if g_ext is not None:
+            # the caller's loss: its gradient replaces this engine's (the [N, V] part of a fresh [N, Vp] buffer -- the logits handed
+            # out stay as they are)
+            g_logits = torch.zeros_like(logits)
+            g_logits[:, :self.V].copy_(g_ext.reshape(Nd, self.V))
+            if tr["head.bias"]:
+                self._defer_colsum(g_logits, fl.g("head.bias", rows=self.Vp))
+        elif tr["head.bias"] and self.Vp % 8 == 0:
             # in place: logits := d loss / d logits; the LM-head bias gradient leaves the same pass as partial column sums
             pb = torch.empty((lib().kvq_ce_bwd_partial_rows(N), self.Vp), dtype=torch.float32, device=self.dev)
             check(lib().kvq_ce_backward_bias(logits.data_ptr(), tgt.data_ptr(), row_lse.data_ptr(), g_scale.data_ptr(), N, self.V,
@@ -1315,14 +1424,17 @@ class TrainEngine:
         gE = self.gE.data_ptr() if self.E.requires_grad else None
         if G == 1:
             g_z = torch.empty_like(z)
-            gl = self._g_vq
+            gl = self._g_vq if self._g_vq_ext is None else self._g_vq_ext
             check(lib().kvq_vq_backward(z.data_ptr(), self.E.data_ptr(), idx.data_ptr(), g_enc.data_ptr(), gl.data_ptr(), N, K, H, 1,
                                         self.io, self.beta_vq, g_z.data_ptr(), gE, ws.data_ptr(), ws.numel(), stream_ptr()),
                   "kvq_vq_backward")
             return g_z
         vq = self.model.vector_quantizer
         zg, gq = vq.split(z), vq.split(g_enc)
-        gl = torch.full((G,), self.w_vq * vq.loss_weight, dtype=torch.float32, device=self.dev)
+        if self._g_vq_ext is None:
+            gl = torch.full((G,), self.w_vq * vq.loss_weight, dtype=torch.float32, device=self.dev)
+        else:
+            gl = (self._g_vq_ext * vq.loss_weight).expand(G).contiguous()
         gzg = torch.empty_like(zg)
         check(lib().kvq_vq_backward(zg.data_ptr(), self.E.data_ptr(), idx.data_ptr(), gq.data_ptr(), gl.data_ptr(), N, K, Dg, G,
                                     self.io, self.beta_vq, gzg.data_ptr(), gE, ws.data_ptr(), ws.numel(), stream_ptr()),
@@ -1380,7 +1492,7 @@ class TrainEngine:
         N, K = logits.shape
         g_y = self._mm(g_zq, emb, "nt")
         self.g_emb.copy_(self._mm(y, g_zq, "tn"))
-        gd = self._ones.reshape(1) * self.w_vq
+        gd = self._ones.reshape(1) * self.w_vq if self._g_vq_ext is None else self._g_vq_ext.reshape(1)
         g_logits = torch.empty_like(logits)
         check(lib().kvq_gumbel_backward(logits.data_ptr(), y_soft.data_ptr(), g_y.data_ptr(), gd.data_ptr(), N, K, float(gq.temperature),
                                         float(gq.kld_scale), self.io, g_logits.data_ptr(), stream_ptr()), "kvq_gumbel_backward")

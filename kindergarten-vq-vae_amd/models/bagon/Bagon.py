@@ -105,7 +105,20 @@ class Bagon(nn.Module):
         from kvq.engine import TrainEngine
         return TrainEngine.supports(self, max(t.shape[1] for t in ids))
 
+    def _engine_autograd_ok(self, *ids) -> bool:
+        """autograd_backend = "engine" (default "aten"): a forward WITH autograd also runs on the engine's kernels, its backward is
+        the engine's backward schedule seeded with the caller's d L / d logits (kvq.engine.engine_autograd_forward).  Covers the
+        autoencoding call (decoder input = encoder input), one process, eager."""
+        if self.backend != "kvq" or not torch.is_grad_enabled() or getattr(self, "autograd_backend", "aten") != "engine" \
+                or not all(t.is_cuda for t in ids) or any(t is not ids[0] for t in ids):
+            return False
+        from kvq.engine import TrainEngine
+        return TrainEngine.supports(self, max(t.shape[1] for t in ids))
+
     def forward(self, encoder_input_ids, encoder_attention_mask, decoder_input_ids, decoder_attention_mask):
+        if self._engine_autograd_ok(encoder_input_ids, decoder_input_ids):
+            from kvq.engine import engine_autograd_forward
+            return engine_autograd_forward(self, encoder_input_ids, encoder_attention_mask)[0]
         if self._engine_forward_ok(encoder_input_ids, decoder_input_ids):
             from kvq.engine import engine_of
             same = decoder_input_ids is encoder_input_ids

@@ -60,6 +60,10 @@ class Shelgon(Bagon):
             from kvq.engine import engine_of
             out = engine_of(self).forward_logits(input_ids, attention_mask, training=self.training, quantizer_training=is_training)
             return out["loss_vq_raw"], out["perplexity"], out["indices"], out["logits"]
+        if self._engine_autograd_ok(input_ids):                                    # autograd wanted AND opted in: still the engine
+            from kvq.engine import engine_autograd_forward
+            logits, vq_loss, perplexity, indices = engine_autograd_forward(self, input_ids, attention_mask, q_training=is_training)
+            return vq_loss, perplexity, indices, logits
         embeds = self.encode(input_ids, attention_mask)                            # Shelgon.py:52
         vq_loss, z_q, perplexity, indices = self._quantize(embeds, device)
         logits = self.decode(z_q, input_ids, attention_mask)                       # Shelgon.py:71

@@ -275,3 +275,35 @@ def test_engine_lm_head_with_loss_statistics_option(monkeypatch):
             continue
         err = (g - g0[n]).norm().item() / max(g0[n].norm().item(), 1e-30)
         assert err < 3e-2, f"{n}: relative L2 difference {err:.3g}"
+
+
+def test_forward_with_autograd_on_the_engine_at_bert_base_shapes():
+    """bf16, bert-base widths, 2048 tokens (own GEMMs, grouped weight gradients, the all-layer cross-K/V GEMM): loss.backward() on
+    the engine-backed forward (model.autograd_backend = "engine") with the caller computing the step's own loss -- mean token cross
+    entropy + quantiser loss -- leaves the gradients of TrainEngine.forward_backward on the same batch: the two runs share every
+    kernel but the loss gradient (torch's log-softmax on the bf16 logits here, kvq_ce_backward there).  Stated tolerance: relative
+    L2 < 1e-2 per tensor."""
+    from kvq.engine import TrainEngine, engine_of
+    model = _build(torch.bfloat16)
+    ids, mask = _batch()
+    eng = engine_of(model)
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+    want = {n: eng.flat.g(n).float().clone() for n, p in eng.param_of.items() if p.requires_grad}
+    want_E = eng.gE.float().clone()
+    model.autograd_backend = "engine"
+    for p in model.parameters():
+        p.grad = None
+    l_vq, perp, idx, logits = model.forward(ids, mask, ids.device, False)
+    assert type(logits.grad_fn).__name__.startswith("_EngineForward") and logits.dtype == torch.bfloat16
+    assert torch.equal(idx, out["indices"])
+    loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), ids.reshape(-1)) + l_vq
+    np.testing.assert_allclose(loss.item(), out["loss_recon"].item() + out["loss_vq"].item(), rtol=1e-3)
+    loss.backward()
+    worst = (0.0, "")
+    for n, p in eng.param_of.items():
+        if p.requires_grad and not n.endswith("k.b"):
+            err = ((p.grad.float() - want[n]).norm() / want[n].norm().clamp_min(1e-30)).item()
+            worst = max(worst, (err, n))
+    E = model.vector_quantizer.embedding.weight
+    assert ((E.grad.float() - want_E).norm() / want_E.norm()).item() < 1e-3
+    assert worst[0] < 1e-2, worst

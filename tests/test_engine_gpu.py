@@ -62,6 +62,56 @@ def test_engine_f32_matches_autograd(mode):
     torch.testing.assert_close(eng.gE, model.vector_quantizer.embedding.weight.grad, rtol=1e-4, atol=1e-8)
 
 
+@pytest.mark.parametrize("mode", ["full", "dec-head-ft"])
+def test_forward_with_autograd_on_the_engine_equals_the_aten_path(mode):
+    """model.autograd_backend = "engine": Shelgon.forward under autograd runs the engine's kernels, and loss.backward() on a loss
+    the CALLER builds from the returned logits and quantiser loss (here a label-smoothed cross entropy, not the engine's own)
+    runs the engine's backward schedule seeded with d L / d logits and d L / d loss_vq.  Same outputs and the same .grad on
+    every trainable parameter as the ATen restatement (kvq/bert.py) under torch autograd; a second backward on new inputs
+    accumulates into .grad like any other op."""
+    import torch.nn.functional as F
+    model = _build(torch.float32, mode).eval()
+    ids, mask = _batch()
+
+    def user_loss(logits, l_vq):
+        return F.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), ids.reshape(-1), label_smoothing=0.1) + 0.7 * l_vq
+
+    runs = {}
+    for backend in ("aten", "engine"):
+        model.autograd_backend = backend
+        for p in model.parameters():
+            p.grad = None
+        l_vq, perp, idx, logits = model.forward(ids, mask, ids.device, False)
+        assert logits.requires_grad and type(logits.grad_fn).__name__.startswith("_EngineForward") == (backend == "engine")
+        loss = user_loss(logits, l_vq)
+        loss.backward()
+        runs[backend] = (loss.item(), l_vq.item(), perp.item(), idx.clone(), logits.detach().float().clone(),
+                         {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    a, e = runs["aten"], runs["engine"]
+    np.testing.assert_allclose(e[0], a[0], rtol=2e-5)
+    np.testing.assert_allclose(e[1], a[1], rtol=2e-5)
+    np.testing.assert_allclose(e[2], a[2], rtol=1e-4)
+    assert torch.equal(e[3], a[3])
+    torch.testing.assert_close(e[4], a[4], rtol=1e-4, atol=1e-4)
+    assert set(e[5]) == set(a[5]) and len(e[5]) > (10 if mode == "full" else 3)
+    for n in a[5]:
+        if not n.endswith("key.bias"):
+            torch.testing.assert_close(e[5][n], a[5][n], rtol=2e-3, atol=2e-6, msg=lambda m: f"{n}: {m}")
+    # accumulation: a second forward / backward on the same batch doubles every gradient
+    model.autograd_backend = "engine"
+    l_vq, perp, idx, logits = model.forward(ids, mask, ids.device, False)
+    user_loss(logits, l_vq).backward()
+    n = "vector_quantizer.embedding.weight" if mode == "full" else "decoder.cls.predictions.transform.dense.weight"
+    torch.testing.assert_close(dict(model.named_parameters())[n].grad, 2 * e[5][n], rtol=1e-5, atol=1e-9)
+    # a forward whose activations were consumed cannot be differentiated twice; a stale one is refused
+    from kvq._ffi import KvqError
+    l_vq, perp, idx, logits = model.forward(ids, mask, ids.device, False)
+    loss = user_loss(logits, l_vq)
+    loss.backward(retain_graph=True)
+    with pytest.raises(KvqError):
+        loss.backward()
+
+
 def test_engine_adam_step_matches_torch_adam():
     from kvq.engine import TrainEngine
     model = _build(torch.float32)
