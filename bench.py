@@ -28,6 +28,7 @@ import torch.distributed as dist  # noqa: E402
 
 BERT_BASE = dict()   # BertConfig() defaults = bert-base-uncased architecture
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparsity headline figure is twice that)
 HBM_PEAK_GBPS = 8000.0         # HBM3E spec
 
 
@@ -200,6 +201,14 @@ def main():
         dist_alg = N_tok * D * es + a.codes * D * 4 + N_tok * 8
         dist_floor = N_tok * D * es + 8 * a.codes * D * 4 + N_tok * 8
         ach_tflops = flops / (vq_avg_ms * 1e-3) / 1e12 if vq_ms else None
+        # matrix-product FLOPs of one step (forward + input gradients + weight gradients of the trainable part = 3 x forward in
+        # `full` mode), from the model's dimensions: every nn.Linear, the two attention products per head, the LM head
+        ce, cd = model.encoder.config, model.decoder.config
+        H, Fi, S = ce.hidden_size, ce.intermediate_size, a.seq_len
+        per_tok_enc = ce.num_hidden_layers * (2 * (4 * H * H + 2 * H * Fi) + 4 * S * H)
+        per_tok_dec = cd.num_hidden_layers * (2 * (8 * H * H + 2 * H * Fi) + 8 * S * H) + 2 * H * H + 2 * H * cd.vocab_size
+        step_flops = 3.0 * N_tok * (per_tok_enc + per_tok_dec) + 3.0 * flops
+        step_s = elapsed / a.steps
         out = {
             "metric": "dSentences train sentences/sec",
             "value": world * a.batch * a.steps / elapsed,
@@ -216,6 +225,9 @@ def main():
             "graph": bool(engine is not None and engine._graphs),      # False = the step ran as ~800 eager launches (capture failed or off)
             "rccl_ranks": rccl_ranks, "dist_backend": (dist.get_backend() if grouped else None),
             "exposed_comm_ms_per_step": exposed_ms,
+            # the whole step against the dense bf16 matrix-core peak (per GPU; a reading aid: `roofline` below is the contract's object)
+            "step_mfma": {"flops_per_step": step_flops, "achieved": step_flops / step_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": step_flops / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS} if a.mode == "full" else None,
             "roofline": {
                 "kernel": "vq_dist_packed_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": (ach_tflops / F32_MFMA_PEAK_TFLOPS) if ach_tflops else None,
