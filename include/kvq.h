@@ -236,8 +236,8 @@ int64_t kvq_gelu_bwd_partial_rows(int64_t N);
 int kvq_gelu_bwd_bias(const void* h, const void* g_a, void* g_h, int64_t N, int64_t C, int io_dtype, float* bias_part,
                       size_t part_bytes, void* stream);
 
-/* BertSelfAttention / BertCrossAttention core (:111-204) for S_q, S_k <= 32 and head dim 64: softmax(q k^T * scale + mask) v
- * with dropout on the probabilities.  q [B*Sq, ldq], k/v [B*Sk, ldk/ldv], out [B*Sq, ldo]; head h lives at columns h*64..;
+/* BertSelfAttention / BertCrossAttention core (:111-204) for S_q, S_k <= 32 (bf16 with 16-byte aligned rows: <= 128, in 32-token
+ * blocks) and head dim 64: softmax(q k^T * scale + mask) v with dropout on the probabilities.  q [B*Sq, ldq], k/v [B*Sk, ldk/ldv], out [B*Sq, ldo]; head h lives at columns h*64..;
  * mask [B,Sk] int64 (1 = attend) or NULL; causal != 0 adds key <= query.  lse [B,nh,Sq] (may be NULL). */
 int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mask, int B, int nh, int Sq, int Sk, int dh,
                  int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed, uint32_t site,
@@ -246,6 +246,14 @@ int kvq_attn_bwd(const void* q, const void* k, const void* v, const int64_t* mas
                  int Sk, int dh, int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed,
                  uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v, float* bias_part_q, float* bias_part_k,
                  float* bias_part_v, int ldp_q, int ldp_kv, void* stream);
+/* The same backward with the forward's output `out` [B*Sq, ldo] and `lse` [B,nh,Sq] handed back: REQUIRED above 32 tokens (the
+ * blocked kernels recompute the probabilities from lse and take delta = rowsum(g_out * out) from `out`; no atomics: one kernel
+ * for g_q over (sentence, head, query block), one for g_k / g_v over (sentence, head, key block)); at <= 32 tokens both are
+ * ignored and the call is kvq_attn_bwd. */
+int kvq_attn_bwd_saved(const void* q, const void* k, const void* v, const int64_t* mask, const void* out, const float* lse,
+                       const void* g_out, int B, int nh, int Sq, int Sk, int dh, int ldq, int ldk, int ldv, int ldo, int causal,
+                       float scale, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* g_q, void* g_k, void* g_v,
+                       float* bias_part_q, float* bias_part_k, float* bias_part_v, int ldp_q, int ldp_kv, void* stream);
 /* bias_part_* (each may be NULL): per-batch column sums of g_q / g_k / g_v, [B][ldp_q] resp. [B][ldp_kv] f32, columns
  * 0 .. nh*64 -- the partial rows of the q/k/v projection bias gradients (modeling_bert.py:83-85 biases), to be finished by
  * kvq_reduce_batch over the B rows.  The MFMA kernels emit them on the way out; the other flavours run a column-sum pass. */

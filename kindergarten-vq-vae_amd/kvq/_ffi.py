@@ -83,6 +83,8 @@ SIGNATURES = {
                             C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp]),
     "kvq_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32,
                             C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
+    "kvq_attn_bwd_saved": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32,
+                                  C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
     "kvq_gemm_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_grouped_bf16": (_int, [C.POINTER(GemmProblem), _int, _int, _int, _vp]),
     "kvq_fp8_quantize": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp, _vp]),

@@ -4,7 +4,7 @@ Plain torch ops (F.linear, F.scaled_dot_product_attention, F.layer_norm, F.gelu,
 BertModel / BertLMHeadModel (so state dicts, init and checkpoints stay those of the reference: models/bagon/Bagon.py:24-31).
 This is NOT the product's execution plan: the hand-written HIP schedule lives in kvq/engine.py (training steps, and every
 Bagon / Shelgon.forward call made without autograd).  This file is what runs when torch autograd must differentiate the model
-(USE_ENGINE = False, sequences longer than 32 tokens, head widths other than 64) and it is the checker the engine's
+(USE_ENGINE = False, sequences longer than the engine's attention kernels take -- 128 tokens in bf16, 32 in f32 --, head widths other than 64) and it is the checker the engine's
 gradients are compared with in tests/test_engine_gpu.py.  Differences from HF's module-by-module forward:
 
   * one fused QKV projection per self-attention ([768 -> 2304] GEMM instead of three), one fused KV projection per

@@ -884,17 +884,20 @@ class TrainEngine:
             kvbuf = kv_pre if kv_pre is not None else \
                 self._linear(kv_src, None, None, fused=([pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"]))
             q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
-        ctx, _ = nnops.attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a)
+        ctx, lse = nnops.attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a)
         ao = self._linear(ctx, pre + "o.w", pre + "o.b")
         out, lnpre, mean, rstd = nnops.ln_fwd(ao, x, fl.w32(pre + "ln.w"), fl.w32(pre + "ln.b"), cfg.layer_norm_eps,
                                               p_hid, self._step_seed, site_o)
-        return out, (x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk)
+        # (lse: only the kernels above 32 tokens work from the saved log-sum-exp)
+        return out, (x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk,
+                     lse if max(Sq, Sk) > 32 else None)
 
     def _attn_block_bwd(self, pre, g_out, saved, g_kv_src=None, g_kv_out=None, pb_kv_out=None):
         """returns g_x; for cross-attention accumulates the gradient of kv_src into g_kv_src -- or, in the batched layout, only
         leaves g_kv (and its bias partial rows) in the given column slices for the all-layer GEMMs after the decoder loop."""
         fl, H, nh = self.flat, self.H, self.nh
-        x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk = saved
+        x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk, lse = saved
+        long_kw = dict(ctx=ctx, lse=lse) if lse is not None else {}
         tr = fl.trainable
         g_ao, g_x = self._ln_bwd(g_out, lnpre, mean, rstd, fl.w32(pre + "ln.w"), p_hid, self._step_seed, site_o,
                                  g_gamma=fl.g(pre + "ln.w") if tr[pre + "ln.w"] else None,
@@ -910,7 +913,7 @@ class TrainEngine:
             pb = torch.empty((B, 3 * H), dtype=torch.float32, device=self.dev) if want_b else None
             nnops.attn_bwd(q, k, v, mask, g_ctx, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a,
                            g_qkv[:, :H], g_qkv[:, H:2 * H], g_qkv[:, 2 * H:],
-                           *((pb[:, :H], pb[:, H:2 * H], pb[:, 2 * H:]) if want_b else ()))
+                           *((pb[:, :H], pb[:, H:2 * H], pb[:, 2 * H:]) if want_b else ()), **long_kw)
             if want_b:
                 self._defer(pb, fl.fused([pre + "q.b", pre + "k.b", pre + "v.b"], fl.grad), B, 3 * H, 3 * H)
             self._linear_bwd(g_qkv, x, [pre + "q.w", pre + "k.w", pre + "v.w"], [pre + "q.b", pre + "k.b", pre + "v.b"], gx_accum=g_x,
@@ -922,7 +925,8 @@ class TrainEngine:
             want_bkv = tr[pre + "k.b"]
             pbkv = (pb_kv_out if batched else torch.empty((B, 2 * H), dtype=torch.float32, device=self.dev)) if want_bkv else None
             nnops.attn_bwd(qkv, kvbuf[:, :H], kvbuf[:, H:], mask, g_ctx, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a,
-                           g_qkv, g_kv[:, :H], g_kv[:, H:], pbq, pbkv[:, :H] if want_bkv else None, pbkv[:, H:] if want_bkv else None)
+                           g_qkv, g_kv[:, :H], g_kv[:, H:], pbq, pbkv[:, :H] if want_bkv else None, pbkv[:, H:] if want_bkv else None,
+                           **long_kw)
             if want_b:
                 self._defer(pbq, fl.g(pre + "q.b"), B, H, H)
             self._linear_bwd(g_qkv, x, [pre + "q.w"], [pre + "q.b"], gx_accum=g_x, bias_done=want_b)
@@ -1079,8 +1083,9 @@ class TrainEngine:
         self._adam_hi, self._adam_forked = self.flat.n, False
         self._stop_after_quantizer = bool(stop_after_quantizer) and not compute_grads
         S = max(input_ids.shape[1], dec_ids.shape[1] if dec_ids is not None else 0)
-        if S > 32:
-            raise KvqError(f"TrainEngine: sequence length {S} above the 32-token attention kernel (use the autograd path)")
+        if S > (128 if self.dtype == torch.bfloat16 else 32):
+            raise KvqError(f"TrainEngine: sequence length {S} above the attention kernels' limit (32 tokens in f32, 128 in bf16 "
+                           f"through the blocked kernels; use the autograd path)")
         if (compute_grads or defer_backward) and dec_ids is not None:
             raise KvqError("TrainEngine: the backward schedule covers the autoencoding step (decoder input = encoder input)")
         if defer_backward and (compute_grads or self._cap is not None or self._dp):
@@ -1594,10 +1599,13 @@ class TrainEngine:
 
     @staticmethod
     def supports(model, seq_len: int) -> bool:
-        """The engine covers BERT-shaped models with 64-wide heads and sentences of at most 32 tokens."""
+        """The engine covers BERT-shaped models with 64-wide heads and sentences of at most 32 tokens (the benchmarked kernels;
+        up to 128 in bf16 through the blocked attention kernels)."""
         cfg = model.encoder.config
         kind = type(getattr(model, "vector_quantizer", None)).__name__
-        return kind in _QUANTIZERS + ("NoneType",) and cfg.hidden_size // cfg.num_attention_heads == 64 and seq_len <= 32 \
+        s_max = 128 if getattr(model, "compute_dtype", torch.float32) == torch.bfloat16 else 32
+        return kind in _QUANTIZERS + ("NoneType",) and cfg.hidden_size // cfg.num_attention_heads == 64 and seq_len <= s_max \
+            and seq_len <= cfg.max_position_embeddings \
             and cfg.hidden_size % 32 == 0 and next(model.parameters()).is_cuda
 
     def prepare_batch(self, input_ids):

@@ -169,7 +169,7 @@ def attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_drop=0.0, seed=0, site=0, o
 
 
 def attn_bwd(q, k, v, mask, g_ctx, B, nh, Sq, Sk, causal, p_drop, seed, site, g_q, g_k, g_v, bias_part_q=None, bias_part_k=None,
-             bias_part_v=None):
+             bias_part_v=None, ctx=None, lse=None):
     """Writes g_q / g_k / g_v (same layouts / row strides as q / k / v).  bias_part_* (f32 2-D views with B rows, row stride
     free, k and v sharing one) receive the per-batch column sums of g_q / g_k / g_v = partial rows of the projection-bias gradients."""
     dh = 64
@@ -180,6 +180,14 @@ def attn_bwd(q, k, v, mask, g_ctx, B, nh, Sq, Sk, causal, p_drop, seed, site, g_
     for t in (bias_part_q, bias_part_k, bias_part_v):
         assert t is None or (t.dtype == torch.float32 and t.shape[0] == B and t.shape[1] >= nh * dh and t.stride(1) == 1)
     assert bias_part_k is None or bias_part_v is None or bias_part_k.stride(0) == bias_part_v.stride(0)
+    if ctx is not None and lse is not None:       # the forward's output and log-sum-exp: what the kernels above 32 tokens work from
+        assert ctx.stride(0) == g_ctx.stride(0) and lse.is_contiguous() and lse.dtype == torch.float32
+        check(lib().kvq_attn_bwd_saved(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(mask), ctx.data_ptr(), lse.data_ptr(), g_ctx.data_ptr(),
+                                       B, nh, Sq, Sk, dh, q.stride(0), k.stride(0), v.stride(0), g_ctx.stride(0), int(causal), 1.0 / 8.0,
+                                       float(p_drop), int(seed), int(site), io_dtype_of(q), g_q.data_ptr(), g_k.data_ptr(), g_v.data_ptr(),
+                                       _p(bias_part_q), _p(bias_part_k), _p(bias_part_v), int(ldp_q), int(ldp_kv), stream_ptr()),
+              "kvq_attn_bwd_saved")
+        return
     check(lib().kvq_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(mask), g_ctx.data_ptr(), B, nh, Sq, Sk, dh, q.stride(0),
                              k.stride(0), v.stride(0), g_ctx.stride(0), int(causal), 1.0 / 8.0, float(p_drop), int(seed), int(site),
                              io_dtype_of(q), g_q.data_ptr(), g_k.data_ptr(), g_v.data_ptr(), _p(bias_part_q), _p(bias_part_k),

@@ -307,3 +307,27 @@ def test_forward_with_autograd_on_the_engine_at_bert_base_shapes():
     E = model.vector_quantizer.embedding.weight
     assert ((E.grad.float() - want_E).norm() / want_E.norm()).item() < 1e-3
     assert worst[0] < 1e-2, worst
+
+
+def test_engine_bf16_at_bert_base_shapes_with_64_token_sentences():
+    """32 sentences x 64 tokens = 2048 tokens at bert-base widths (12 heads: 768 (sentence, head, block) waves per attention launch):
+    the blocked attention kernels inside the engine's step, against f32 autograd through HuggingFace's forward -- the bounds of the
+    32-token bf16 test above."""
+    from kvq.engine import TrainEngine
+    ids, mask = _batch(B=32, S=64, seed=4)
+    m32 = _build(torch.float32)
+    ref = _hf_autograd(m32, ids, mask)
+    del m32
+    model = _build(torch.bfloat16)
+    eng = TrainEngine(model, lr=1e-4)
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+    np.testing.assert_allclose(out["loss_recon"].item(), ref["loss_recon"], rtol=2e-2)
+    np.testing.assert_allclose(out["loss_vq"].item(), ref["loss_vq"], rtol=5e-2)
+    assert (out["indices"] == ref["idx"]).float().mean().item() > 0.97
+    cos = []
+    for n, g in _engine_grads(eng, model).items():
+        r = ref["grads"][n]
+        if r.norm() > 0 and not n.endswith("key.bias"):
+            cos.append((n, F.cosine_similarity(g.reshape(-1), r.reshape(-1), dim=0).item()))
+    worst = min(cos, key=lambda t: t[1])
+    assert worst[1] > 0.97 and np.mean([c for _, c in cos]) > 0.997, (worst, np.mean([c for _, c in cos]))

@@ -318,6 +318,89 @@ def test_attention_dropout_mask_consistency(ops):
     torch.testing.assert_close(gv, unh(vr.grad), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,nh,Sq,Sk,causal,masked", [(3, 12, 64, 64, False, True), (2, 4, 64, 64, True, True), (2, 3, 48, 48, True, True),
+                                                      (2, 2, 33, 33, True, False), (2, 2, 100, 100, True, True), (2, 2, 128, 128, False, True),
+                                                      (2, 2, 40, 96, False, True), (1, 3, 70, 20, False, False), (2, 2, 20, 70, False, True)])
+def test_attention_above_32_tokens(ops, B, nh, Sq, Sk, causal, masked):
+    """The blocked bf16 kernels (33 .. 128 tokens, 32-token blocks, running softmax forward; dQ and dK/dV kernels backward from the
+    saved output and log-sum-exp) against the f32 BertSelfAttention math: full and ragged last blocks, key-padding masks, causal
+    self-attention, cross-attention with different lengths on either side.  bf16 tolerances of the 32-token kernels."""
+    dtype = torch.bfloat16
+    torch.manual_seed(B * 100 + Sq + Sk)
+    H = nh * 64
+    qkv = torch.randn(B * Sq, 3 * H, device="cuda").to(dtype)
+    kv = torch.randn(B * Sk, 2 * H, device="cuda").to(dtype)
+    if Sq == Sk:
+        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    else:
+        q, k, v = qkv[:, :H], kv[:, :H], kv[:, H:]
+    mask = None
+    if masked:
+        lens = torch.randint(1, Sk + 1, (B,), device="cuda")
+        lens[0] = Sk
+        mask = (torch.arange(Sk, device="cuda")[None] < lens[:, None]).long()
+    ctx, lse = ops.attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal)
+    heads = lambda t, S: t.float().reshape(B, S, nh, 64).transpose(1, 2).detach().clone().requires_grad_(True)
+    qr, kr, vr = heads(q, Sq), heads(k, Sk), heads(v, Sk)
+    ref = _ref_attention(qr, kr, vr, mask, causal)
+    torch.testing.assert_close(ctx.float(), ref.transpose(1, 2).reshape(B * Sq, H), **_tol(dtype))
+    s = (qr @ kr.transpose(-1, -2) / 8.0).detach()
+    allow = torch.ones(B, 1, Sq, Sk, dtype=torch.bool, device="cuda")
+    if mask is not None:
+        allow = allow & mask.bool()[:, None, None, :]
+    if causal:
+        allow = allow & torch.ones(Sq, Sk, dtype=torch.bool, device="cuda").tril()[None, None]
+    torch.testing.assert_close(lse, torch.logsumexp(s.masked_fill(~allow, float("-inf")), -1), rtol=1e-3, atol=2e-2)
+    g = torch.randn(B * Sq, H, device="cuda").to(dtype)
+    ref.backward(g.float().reshape(B, Sq, nh, 64).transpose(1, 2))
+    gbuf_q = torch.zeros_like(qkv); gbuf_kv = torch.zeros_like(kv)
+    if Sq == Sk:
+        gq, gk, gv = gbuf_q[:, :H], gbuf_q[:, H:2 * H], gbuf_q[:, 2 * H:]
+    else:
+        gq, gk, gv = gbuf_q[:, :H], gbuf_kv[:, :H], gbuf_kv[:, H:]
+    pbq = torch.full((B, H), 7.0, device="cuda"); pbkv = torch.full((B, 2 * H), 7.0, device="cuda")
+    from kvq._ffi import KvqError
+    with pytest.raises(KvqError):                       # without the forward's output / lse the long kernels cannot run
+        ops.attn_bwd(q, k, v, mask, g, B, nh, Sq, Sk, causal, 0.0, 0, 0, gq, gk, gv)
+    ops.attn_bwd(q, k, v, mask, g, B, nh, Sq, Sk, causal, 0.0, 0, 0, gq, gk, gv, pbq, pbkv[:, :H], pbkv[:, H:], ctx=ctx, lse=lse)
+    bt = dict(rtol=1e-2, atol=1e-1)
+    torch.testing.assert_close(pbq, gq.float().reshape(B, Sq, H).sum(1), **bt)
+    torch.testing.assert_close(pbkv[:, :H], gk.float().reshape(B, Sk, H).sum(1), **bt)
+    torch.testing.assert_close(pbkv[:, H:], gv.float().reshape(B, Sk, H).sum(1), **bt)
+    unh = lambda t, S: t.transpose(1, 2).reshape(B * S, H)
+    t = _tol(dtype)
+    torch.testing.assert_close(gq.float(), unh(qr.grad, Sq), **t)
+    torch.testing.assert_close(gk.float(), unh(kr.grad, Sk), **t)
+    torch.testing.assert_close(gv.float(), unh(vr.grad, Sk), **t)
+
+
+def test_attention_above_32_tokens_dropout_mask_consistency(ops):
+    """64 tokens with dropout: the mask is revealed through q = 0, V = one-hot rows (bf16 holds 1 / (64 * 0.9) to 3 digits: a kept
+    entry is simply non-zero); forward and both backward kernels must then agree with the f32 math under THAT mask."""
+    B, nh, S, p = 2, 3, 64, 0.1
+    H = nh * 64
+    bf = torch.bfloat16
+    z = torch.zeros(B * S, H, device="cuda", dtype=bf)
+    eye = torch.zeros(S, 64, device="cuda"); eye[torch.arange(S), torch.arange(S)] = 1
+    v1 = eye[None, :, None, :].expand(B, S, nh, 64).reshape(B * S, H).contiguous().to(bf)
+    ctx, _ = ops.attn_fwd(z, z, v1, None, B, nh, S, S, False, p, seed=99, site=3)
+    keep = (ctx.float().reshape(B, S, nh, 64).permute(0, 2, 1, 3) > 0).float()          # [b, h, i, j]
+    assert abs((1 - keep.mean().item()) - p) < 0.02
+    torch.manual_seed(5)
+    q, k, v, g = (torch.randn(B * S, H, device="cuda").to(bf) for _ in range(4))
+    heads = lambda t: t.float().reshape(B, S, nh, 64).transpose(1, 2).detach().clone().requires_grad_(True)
+    qr, kr, vr = heads(q), heads(k), heads(v)
+    ref = _ref_attention(qr, kr, vr, None, True, keep, p)
+    ctx, lse = ops.attn_fwd(q, k, v, None, B, nh, S, S, True, p, seed=99, site=3)
+    torch.testing.assert_close(ctx.float(), ref.transpose(1, 2).reshape(B * S, H), **_tol(bf))
+    ref.backward(g.float().reshape(B, S, nh, 64).transpose(1, 2))
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.attn_bwd(q, k, v, None, g, B, nh, S, S, True, p, 99, 3, gq, gk, gv, ctx=ctx, lse=lse)
+    unh = lambda t: t.transpose(1, 2).reshape(B * S, H)
+    for got, want in ((gq, qr.grad), (gk, kr.grad), (gv, vr.grad)):
+        torch.testing.assert_close(got.float(), unh(want), **_tol(bf))
+
+
 @pytest.mark.parametrize("amsgrad,wd", [(False, 0.0), (True, 0.01)])
 @pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
 def test_adam_matches_torch(ops, amsgrad, wd, gdtype):
