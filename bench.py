@@ -262,7 +262,9 @@ def main():
         elif engine is not None and not out["graph"] and os.environ.get("KVQ_GRAPH", "1") != "0" and a.warmup + a.steps > 3:
             print("[bench] the step was NOT replayed from hipGraphs (capture failed) although KVQ_GRAPH=0 was not asked for",
                   file=sys.stderr)
-            bad = 4
+            # one GPU: the line would describe another program than the one that is meant to be measured -> fail.  Several ranks: the
+            # eager step is the documented fallback of a capture that the collective library refused; the line says "graph": false
+            bad = 4 if world == 1 else 0
         else:
             bad = 0
     else:
