@@ -135,6 +135,30 @@ template <> struct ZRaw<KVQ_BF16> {
     }
 };
 
+// Diagnostic build only (-DKVQ_VQ_DIAG, tools/build_diag.sh; the product library has none of this): thread 0 of every workgroup
+// times its prologue, its stages and its stage barriers with s_memtime and stores [workgroup][8] u64 at its end.
+#ifdef KVQ_VQ_DIAG
+// (stamps stored from inside the stage loop made the kernel five times slower: the loop only ACCUMULATES two scalar differences
+//  -- time inside the stage barriers, time between them -- and the workgroup stores five numbers at its end)
+__device__ unsigned long long* g_vq_diag = nullptr;
+#define VQ_DIAG_DECL unsigned long long vq_t_entry = __builtin_amdgcn_s_memtime(), vq_t_prev = 0, vq_t_bar = 0, vq_acc_bar = 0, vq_acc_stage = 0, vq_t_pro = 0;
+#define VQ_DIAG_PROLOGUE { vq_t_pro = __builtin_amdgcn_s_memtime(); vq_t_prev = vq_t_pro; }
+#define VQ_DIAG_BEFORE_BARRIER { vq_t_bar = __builtin_amdgcn_s_memtime(); vq_acc_stage += vq_t_bar - vq_t_prev; }
+#define VQ_DIAG_AFTER_BARRIER { vq_t_prev = __builtin_amdgcn_s_memtime(); vq_acc_bar += vq_t_prev - vq_t_bar; }
+#define VQ_DIAG_END                                                                                                  \
+    if (g_vq_diag != nullptr && threadIdx.x == 0) {                                                                  \
+        unsigned long long* o = g_vq_diag + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 8;                       \
+        o[0] = vq_t_entry; o[1] = vq_t_pro; o[2] = vq_acc_stage; o[3] = vq_acc_bar; o[4] = vq_t_prev;                \
+        o[5] = __builtin_amdgcn_s_memtime(); o[6] = __builtin_amdgcn_s_memrealtime();                                \
+    }
+#else
+#define VQ_DIAG_DECL
+#define VQ_DIAG_PROLOGUE
+#define VQ_DIAG_BEFORE_BARRIER
+#define VQ_DIAG_AFTER_BARRIER
+#define VQ_DIAG_END
+#endif
+
 // (Round 2 also measured the token operand loaded straight into registers in B-fragment layout -- no LDS, no barrier, waves fully
 //  decoupled, same bits: 81 us against 65.5 us for this kernel at N = 8192, K = 512, D = 768.  The LDS stage is not what idles the
 //  matrix pipe.  Four token tiles per wave -- 128 tokens per workgroup, one workgroup per CU, every codebook fragment used for
@@ -148,6 +172,7 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
     constexpr int TMW = 32 * TT;                              // tokens per workgroup
     constexpr int ZSTAGE = TMW * T3_KC;                       // floats per z stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    VQ_DIAG_DECL
     const int tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int g = blockIdx.z;
@@ -185,6 +210,7 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
 #pragma unroll
     for (int q = 0; q < 4; ++q) a0[q] = Ap[(size_t)q * 64];
     __syncthreads();
+    VQ_DIAG_PROLOGUE
 
     f32x16 acc[TT];
 #pragma unroll
@@ -238,13 +264,17 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
         if (more1) KVQ_PREFETCH(a1, (ST) + 1)                                                                  \
         KVQ_CLUSTER(a0, 0)                                                                                     \
         if (more1) KVQ_COMMIT(1)                                                                               \
+        VQ_DIAG_BEFORE_BARRIER                                                                                 \
         __syncthreads();                                                                                       \
+        VQ_DIAG_AFTER_BARRIER                                                                                  \
         if (more1) {                                                                                           \
             const bool more2 = (ST) + 2 < nst;                                                                 \
             if (more2) KVQ_PREFETCH(a0, (ST) + 2)                                                              \
             KVQ_CLUSTER(a1, 1)                                                                                 \
             if (more2) KVQ_COMMIT(0)                                                                           \
+            VQ_DIAG_BEFORE_BARRIER                                                                             \
             __syncthreads();                                                                                   \
+            VQ_DIAG_AFTER_BARRIER                                                                              \
         }                                                                                                      \
     }
     if (NST > 0) {
@@ -258,47 +288,77 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
 #undef KVQ_COMMIT
 #undef KVQ_CLUSTER
 
+    // ---- arg-min over the workgroup's 128 codes, per token.  In-kernel timing (tools/vq_stamps.py) put the first version of this
+    // tail -- a branch per candidate for the validity test, the debug dump and the NaN / tie rule, one ds_bpermute round trip per
+    // candidate for ||e||^2 -- at 14.6 k cycles of a 134 k-cycle workgroup at K = 512 (one round: nothing else uses the matrix
+    // pipe meanwhile).  Now: the 32 ||e||^2 of the wave go through LDS once (four 16-byte reads per lane), every candidate becomes
+    // the 64-bit key the final atomicMin orders by anyway (monotone map of the distance, NaN lowest, then the code), and minima
+    // are integer selects.  Same arithmetic for the distance (fl(fl(z2 + e2) - 2 acc)), same winner: key order == cand_better
+    // order (-0 is canonicalised to +0 first; the two differ in nothing else).
     const float e2v = pe + __shfl_xor(pe, 32, WAVE);
     const int cbase = code0 + w * 32;
-    float* red_val = smem;                                   // (dead) z stages: [4 waves][TMW] floats + ints
-    int* red_idx = reinterpret_cast<int*>(smem + T2_WAVES * TMW);
+    float* e2s = smem + T2_WAVES * 2 * TMW + 32 * w;          // behind the merge buffers; 32 floats per wave (z stages are dead)
+    unsigned long long* red_key = reinterpret_cast<unsigned long long*>(smem);     // [4 waves][TMW]
+    if (lane < 32) e2s[i] = e2v;                              // (same wave writes and reads: LDS operations of a wave stay in order)
+    f32x4 e2q[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e2q[q] = *reinterpret_cast<const f32x4*>(e2s + 8 * q + 4 * h);
+    if (p.dump) {                                             // debug hook (wave-uniform): the distances as the arg-min sees them
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const float z2 = pz[t] + __shfl_xor(pz[t], 32, WAVE);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float dd = (z2 + e2q[r >> 2][r & 3]) - 2.0f * acc[t][r];
+                if (wave_has_codes && cbase + cl < p.K && tok0 + 32 * t + i < p.N) p.dump[(size_t)(tok0 + 32 * t + i) * p.K + cbase + cl] = dd;
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         const float z2 = pz[t] + __shfl_xor(pz[t], 32, WAVE);
-        float best = INFINITY;
-        int bidx = INT_MAX;
+        unsigned long long best = ~0ull;
+        if (wave_has_codes && cbase + 32 <= p.K) {            // wave-uniform: every code of this wave exists (the usual case: K a multiple of 32)
+            // a lane's codes ascend with r: a strict "<" on the 32-bit distance key keeps the lowest code among equals
+            unsigned bk = 0xffffffffu;
+            int bc = INT_MAX;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float e2r = __shfl(e2v, cl, WAVE);
-            const float tt = z2 + e2r;
-            const float dd = tt - 2.0f * acc[t][r];
-            const int code = cbase + cl;
-            if (wave_has_codes && code < p.K) {
-                if (p.dump && tok0 + 32 * t + i < p.N) p.dump[(size_t)(tok0 + 32 * t + i) * p.K + code] = dd;
-                if (cand_better(dd, code, best, bidx)) { best = dd; bidx = code; }
+            for (int r = 0; r < 16; ++r) {
+                const float tt = z2 + e2q[r >> 2][r & 3];
+                const float dd = (tt - 2.0f * acc[t][r]) + 0.0f;                   // (+ 0: -0 -> +0, nothing else changes)
+                const unsigned key = (unsigned)(pack_key(dd, 0) >> 32);
+                const bool lt = key < bk;
+                bk = lt ? key : bk;
+                bc = lt ? cbase + (r & 3) + 8 * (r >> 2) + 4 * h : bc;
+            }
+            best = ((unsigned long long)bk << 32) | (unsigned)bc;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float tt = z2 + e2q[r >> 2][r & 3];
+                const float dd = (tt - 2.0f * acc[t][r]) + 0.0f;
+                const int code = cbase + cl;
+                const unsigned long long key = (wave_has_codes && code < p.K) ? pack_key(dd, code) : ~0ull;
+                best = key < best ? key : best;
             }
         }
-        const float ob = __shfl_xor(best, 32, WAVE);
-        const int oi = __shfl_xor(bidx, 32, WAVE);
-        if (cand_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
-        if (lane < 32) {
-            red_val[w * TMW + 32 * t + i] = best;
-            red_idx[w * TMW + 32 * t + i] = bidx;
-        }
+        const unsigned long long other = __shfl_xor(best, 32, WAVE);
+        best = other < best ? other : best;
+        if (lane < 32) red_key[w * TMW + 32 * t + i] = best;
     }
     __syncthreads();
     if (tid < TMW && tok0 + tid < p.N) {
-        float b = red_val[tid];
-        int bi = red_idx[tid];
+        unsigned long long b = red_key[tid];
 #pragma unroll
         for (int ww = 1; ww < T2_WAVES; ++ww) {
-            const float v = red_val[ww * TMW + tid];
-            const int vi = red_idx[ww * TMW + tid];
-            if (cand_better(v, vi, b, bi)) { b = v; bi = vi; }
+            const unsigned long long v = red_key[ww * TMW + tid];
+            b = v < b ? v : b;
         }
-        if (bi != INT_MAX) atomicMin(p.keys + (size_t)g * p.N + tok0 + tid, pack_key(b, bi));
+        if (b != ~0ull) atomicMin(p.keys + (size_t)g * p.N + tok0 + tid, b);
     }
+    VQ_DIAG_END
 }
 
 // epilogue of the v2 path: 64 tokens per workgroup, one wave per token at a time
@@ -764,6 +824,12 @@ static int launch_forward(FwdParams p, int G, bool use_mfma, bool packed, hipStr
 using namespace kvq;
 
 extern "C" {
+
+#ifdef KVQ_VQ_DIAG
+int kvq_vq_diag_set_buffer(void* buf) {       // diagnostic library only: [workgroups of the next launch][8] u64, or null
+    return hipMemcpyToSymbol(HIP_SYMBOL(kvq::g_vq_diag), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 size_t kvq_vq_workspace_bytes(int64_t N, int K, int D, int G) {
     if (N <= 0 || K <= 0 || D <= 0 || G <= 0) return 0;
