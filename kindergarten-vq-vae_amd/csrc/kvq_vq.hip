@@ -188,7 +188,7 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
     const f32x4* __restrict__ Ap = reinterpret_cast<const f32x4*>(p.epack + (size_t)g * ncb * 32 * p.D) + ((size_t)cb * G8) * 64 + lane;
 
     // z staging: TT 16-byte chunks per thread per stage (rows of 128 B, chunk swizzle (row>>1)&7)
-    typename ZRaw<DT>::T zreg[TT];                             // raw 4 elements (converted only when written to LDS)
+    typename ZRaw<DT>::T zreg[TT], zregB[TT];                  // raw 4 elements (converted only when written to LDS); B: the pair's second stage
     int zoff[TT];
     int64_t ztok[TT];
     float zmul[TT];
@@ -201,6 +201,10 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
         zoff[q] = r * T3_KC + ((c ^ ((r >> 1) & 7)) << 2);
         zreg[q] = ZRaw<DT>::load(p.z, zbase + (size_t)ztok[q] * p.D + c * 4);
         *reinterpret_cast<f32x4*>(smem + zoff[q]) = ZRaw<DT>::cvt(zreg[q]) * zmul[q];
+        if (nst > 1) {                                                   // the first PAIR of stages goes in before the first barrier
+            zregB[q] = ZRaw<DT>::load(p.z, zbase + (size_t)ztok[q] * p.D + T3_KC + c * 4);
+            *reinterpret_cast<f32x4*>(smem + ZSTAGE + zoff[q]) = ZRaw<DT>::cvt(zregB[q]) * zmul[q];
+        }
     }
     const int zc4 = (tid & 7) * 4;
     // codebook fragments ping-pong between two NAMED register sets (a0 for even stages, a1 for odd ones): with a
@@ -222,17 +226,18 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
     for (int t = 0; t < TT; ++t) pz[t] = 0.f;
     const int sw = (i >> 1) & 7;
 
-#define KVQ_PREFETCH(AREG, STG)                                                                               \
+#define KVQ_PREFETCH_A(AREG, STG)                                                                             \
+    { _Pragma("unroll") for (int q = 0; q < 4; ++q) AREG[q] = Ap[(size_t)(4 * (STG) + q) * 64]; }
+#define KVQ_PREFETCH_Z(ZREG, STG)                                                                             \
     {                                                                                                          \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) AREG[q] = Ap[(size_t)(4 * (STG) + q) * 64];              \
         _Pragma("unroll") for (int q = 0; q < TT; ++q)                                                         \
-            zreg[q] = ZRaw<DT>::load(p.z, zbase + (size_t)ztok[q] * p.D + (STG) * T3_KC + zc4);                \
+            ZREG[q] = ZRaw<DT>::load(p.z, zbase + (size_t)ztok[q] * p.D + (STG) * T3_KC + zc4);                \
     }
-#define KVQ_COMMIT(BUF)                                                                                        \
+#define KVQ_COMMIT(ZREG, BUF)                                                                                  \
     {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0); /* conversion + LDS write stay BEHIND the MFMA cluster */           \
         _Pragma("unroll") for (int q = 0; q < TT; ++q)                                                         \
-            *reinterpret_cast<f32x4*>(smem + (BUF) * ZSTAGE + zoff[q]) = ZRaw<DT>::cvt(zreg[q]) * zmul[q];     \
+            *reinterpret_cast<f32x4*>(smem + (BUF) * ZSTAGE + zoff[q]) = ZRaw<DT>::cvt(ZREG[q]) * zmul[q];     \
     }
 #define KVQ_CLUSTER(AREG, BUF)                                                                                 \
     {                                                                                                          \
@@ -258,24 +263,26 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
         if (PRIO) __builtin_amdgcn_s_setprio(0);                                                               \
     }
 
+    // ONE barrier per PAIR of stages (round 3; tools/vq_stamps.py put 800 of a stage's 4900 cycles at the stage boundary: commit
+    // of the next z tile, barrier, fragment reads -- with the SIMD's other wave in the same phase).  LDS holds two pairs of stage
+    // buffers; the codebook fragments still ping-pong per stage (they are the wave's own registers: no barrier involved).
 #define KVQ_STAGE_PAIR(ST)                                                                                     \
     {                                                                                                          \
-        const bool more1 = (ST) + 1 < nst;                                                                     \
-        if (more1) KVQ_PREFETCH(a1, (ST) + 1)                                                                  \
-        KVQ_CLUSTER(a0, 0)                                                                                     \
-        if (more1) KVQ_COMMIT(1)                                                                               \
+        const int cur = (((ST) >> 1) & 1) * 2, nxt = cur ^ 2;                                                  \
+        const bool more1 = (ST) + 1 < nst, more2 = (ST) + 2 < nst, more3 = (ST) + 3 < nst;                     \
+        if (more2) KVQ_PREFETCH_Z(zreg, (ST) + 2)                                                              \
+        if (more3) KVQ_PREFETCH_Z(zregB, (ST) + 3)                                                             \
+        if (more1) KVQ_PREFETCH_A(a1, (ST) + 1)                                                                \
+        KVQ_CLUSTER(a0, cur)                                                                                   \
+        if (more1) {                                                                                           \
+            if (more2) KVQ_PREFETCH_A(a0, (ST) + 2)                                                            \
+            KVQ_CLUSTER(a1, cur + 1)                                                                           \
+        }                                                                                                      \
+        if (more2) KVQ_COMMIT(zreg, nxt)                                                                       \
+        if (more3) KVQ_COMMIT(zregB, nxt + 1)                                                                  \
         VQ_DIAG_BEFORE_BARRIER                                                                                 \
         __syncthreads();                                                                                       \
         VQ_DIAG_AFTER_BARRIER                                                                                  \
-        if (more1) {                                                                                           \
-            const bool more2 = (ST) + 2 < nst;                                                                 \
-            if (more2) KVQ_PREFETCH(a0, (ST) + 2)                                                              \
-            KVQ_CLUSTER(a1, 1)                                                                                 \
-            if (more2) KVQ_COMMIT(0)                                                                           \
-            VQ_DIAG_BEFORE_BARRIER                                                                             \
-            __syncthreads();                                                                                   \
-            VQ_DIAG_AFTER_BARRIER                                                                              \
-        }                                                                                                      \
     }
     if (NST > 0) {
 #pragma unroll
@@ -284,7 +291,8 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
         for (int st = 0; st < nst; st += 2) KVQ_STAGE_PAIR(st)
     }
 #undef KVQ_STAGE_PAIR
-#undef KVQ_PREFETCH
+#undef KVQ_PREFETCH_A
+#undef KVQ_PREFETCH_Z
 #undef KVQ_COMMIT
 #undef KVQ_CLUSTER
 
@@ -799,7 +807,7 @@ static int launch_forward(FwdParams p, int G, bool use_mfma, bool packed, hipStr
         if (!packed) launch_pack(p.E, p.K, p.D, G, const_cast<float*>(p.epack), st);
         const bool prof = prof_begin(st);
         dim3 grid((unsigned)((p.N + 63) / 64), (unsigned)((p.K + T2_CN - 1) / T2_CN), (unsigned)G);
-        const size_t lds = 2 * 64 * T3_KC * sizeof(float);
+        const size_t lds = 4 * 64 * T3_KC * sizeof(float);      // two pairs of z stage buffers
         if (p.D == 768) hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 24>), grid, dim3(T2_THREADS), lds, st, p);
         else hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 0>), grid, dim3(T2_THREADS), lds, st, p);
         if (prof) prof_end(st);

@@ -45,6 +45,6 @@ cyc = lambda a: f"median {np.median(a):8.0f} cycles (p10 {np.percentile(a, 10):8
 print("  workgroup lifetime           ", cyc(end - entry))
 print("  entry -> prologue done       ", cyc(pro - entry), " first z tile in LDS, first codebook fragments")
 print("  24 stages, between barriers  ", cyc(acc_stage), f" = {np.median(acc_stage) / 24:.0f} per stage (32 MFMAs of one wave alone: 2048)")
-print("  24 stages, inside the barrier", cyc(acc_bar), f" = {np.median(acc_bar) / 24:.0f} per stage (thread 0's wave waiting for the other three)")
+print("  24 stages, inside the barrier", cyc(acc_bar), f" = {np.median(acc_bar) / 24:.0f} per stage (thread 0's wave waiting for the other three; one barrier per PAIR of stages since round 3)")
 print("  last barrier -> end          ", cyc(end - last_bar), " arg-min, LDS merge, atomicMin")
 print(f"  if the matrix pipe never idled a stage would take 4096 cycles with two waves per SIMD; measured {np.median(acc_stage + acc_bar) / 24:.0f}")
