@@ -3,15 +3,16 @@
 import collections
 import csv
 import glob
+import os
 import sys
 
 run, tag = sys.argv[1], sys.argv[2]
 dur = {}
-for r in csv.DictReader(open(glob.glob(f"{run}/trace/*/*_kernel_stats.csv")[0])):
+for r in csv.DictReader(open(max(glob.glob(f"{run}/trace/*/*_kernel_stats.csv"), key=os.path.getmtime))):
     dur[r["Name"].split("(")[0].replace("void ", "")] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 for p, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    for r in csv.DictReader(open(glob.glob(f"{run}/{p}/*/*counter_collection.csv")[0])):
+    for r in csv.DictReader(open(max(glob.glob(f"{run}/{p}/*/*counter_collection.csv"), key=os.path.getmtime))):
         if r["Counter_Name"] == c:
             cnt[r["Kernel_Name"].split("(")[0].replace("void ", "")][c].append(float(r["Counter_Value"]))
 alg = {"kvq::drln_fwd_kernel<1, 3>": 50.3, "kvq::drln_bwd16_kernel<3>": 55.0, "kvq::attn_fwd_mfma_kernel": 50.3, "kvq::attn_bwd_mfma_kernel": 88.1,

@@ -38,7 +38,7 @@ def groups(pass_name):
 G = {p: groups(p) for p in ("sq", "fetch", "write", "grbm")}
 calib = {}
 for kind in ("fetch", "write"):
-    f = glob.glob(f"{run}/calib_{kind}/*/*counter_collection.csv")
+    f = sorted(glob.glob(f"{run}/calib_{kind}/*/*counter_collection.csv"), key=os.path.getmtime, reverse=True)
     if f:
         for r in csv.DictReader(open(f[0])):
             calib.setdefault((kind, r["Kernel_Name"].split("(")[0][-40:]), []).append(float(r["Counter_Value"]) / 1024)

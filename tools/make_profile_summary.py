@@ -27,7 +27,7 @@ out += ["", f"hipBLASLt/rocBLAS GEMM kernels: {gemm/1e6/steps:.2f} ms/step; libk
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for d in ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"]:
-    f = glob.glob(f"{run}/{d}/*/*_counter_collection.csv")
+    f = sorted(glob.glob(f"{run}/{d}/*/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)   # newest first: a re-run merges next to older files
     if not f:
         continue
     for r in csv.DictReader(open(f[0])):
@@ -60,7 +60,7 @@ dk = [k for k in traffic if "dist_packed" in k]
 # the large-codebook point (BASELINE.json configs[3], K = 8192): traffic passes only
 agg8 = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ["pmc_fetch_k8192", "pmc_write_k8192"]:
-    f = glob.glob(f"{run}/{d}/*/*_counter_collection.csv")
+    f = sorted(glob.glob(f"{run}/{d}/*/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)   # newest first: a re-run merges next to older files
     if f:
         for r in csv.DictReader(open(f[0])):
             if "vq_" in r["Kernel_Name"]:

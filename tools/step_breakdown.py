@@ -4,9 +4,10 @@ usage: step_breakdown.py <dir with *_kernel_trace.csv> [rows]"""
 import collections
 import csv
 import glob
+import os
 import sys
 
-f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)   # (a re-run merges next to older files)
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
