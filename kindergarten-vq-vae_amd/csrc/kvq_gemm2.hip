@@ -597,6 +597,9 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
     // ---- main loop: per k-tile
     //   MFMA(f0) || read f1 || 2nd half of the pending refill  |  f1 ready, tile kt+1 landed, barrier  |
     //   MFMA(f1) || read next f0 || 1st half of the refill of the slot just freed
+#ifdef KVQ_G2_DIAG
+    unsigned long long diag_vm = 0, diag_bar = 0;      // (diagnostic build) cycles of wave 0 in the k loop's vmcnt waits / barriers
+#endif
     Frags<C> f0, f1;
     read_frags<C>(f0, smem, wm, wn, 0, lane);
     // pieces issued inside the first cluster after the barrier; a two-slot ring needs the whole refill there (the tile is
@@ -621,9 +624,20 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
         const bool more = STEADY || kt + 1 < nkt;
         const int nslot = slot + 1 == C::NS ? 0 : slot + 1;
         if (more) {
+#ifdef KVQ_G2_DIAG
+            const unsigned long long t_pre = __builtin_amdgcn_s_memtime();
+            if (STEADY || kt + C::NS <= nkt) wait_vm<(C::NS - 2) * C::PPW>();
+            else wait_vm<0>();
+            const unsigned long long t_mid = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long t_post = __builtin_amdgcn_s_memtime();
+            diag_vm += t_mid - t_pre;                                      // waiting for this wave's DMA pieces of tile kt+1
+            diag_bar += t_post - t_mid;                                    // waiting for the other waves
+#else
             if (STEADY || kt + C::NS <= nkt) wait_vm<(C::NS - 2) * C::PPW>();   // tiles kt+2 .. kt+NS-1 may still be in flight
             else wait_vm<0>();
             __builtin_amdgcn_s_barrier();                                  // tile kt+1 landed for everybody; `slot` is free
+#endif
             pending = STEADY || kt + C::NS < nkt;
             pslot = slot;
         }
@@ -637,7 +651,17 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
     for (; kt + C::NS < nkt; ++kt) ktile(kt, std::true_type{});
     for (; kt < nkt; ++kt) ktile(kt, std::false_type{});
     __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring is free (it becomes the epilogue tile)
+#ifdef KVQ_G2_DIAG
+    G2_STAMP_VAL(12, diag_vm);
+    G2_STAMP_VAL(13, diag_bar);
+#endif
 }
+// (Round 3, measured and removed: an L2 prefetch for the weight-gradient layout.  The in-kernel timers above showed wave 0 of the
+//  256 x 256 TN kernel a quarter of its k loop in the vmcnt wait for its own DMA pieces -- two ring slots mean a k-tile is asked
+//  for one k-tile, ~1.4 us, ahead.  Every thread then touched one 128-byte line of the k-tile four further on with a 4-byte load
+//  (one more entry in the vmcnt queue per k-tile, the counted waits adjusted): the vmcnt share fell to 0.6 %, the barrier share
+//  rose from 13 % to 38 %, the k-tile took 2899 cycles instead of 2856 and the grouped launches 226 / 250 us instead of 215 / 231.
+//  Wave 0's wait was slack, not the loop's pace.)
 
 // one tile of problem `pr`: ring prologue, k loop, epilogue
 template <class C, int EPI>

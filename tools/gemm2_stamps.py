@@ -75,6 +75,11 @@ def us(d):
 
 
 t_setup, t_k0 = s[:, 10], s[:, 11]
+d_vm, d_bar = s[:, 12].astype(np.float64), s[:, 13].astype(np.float64)
+nkt = K // 64
+loop = (t_loop - t_first).astype(np.float64)
+print(f"  k loop of wave 0: {np.median(loop) / nkt:7.0f} cycles per k-tile; of the loop {100 * np.median(d_vm / loop):4.1f} % in the vmcnt wait before the barrier "
+      f"(own DMA pieces not landed), {100 * np.median(d_bar / loop):4.1f} % in the barrier (other waves)   [the two timer reads per k-tile cost ~100 cycles themselves]")
 for name, d in (("  entry -> setup done (tile lookup, bias, offsets)", t_setup - t_entry), ("  setup done -> k-tile 0 issued", t_k0 - t_setup),
                 ("  k-tile 0 issued -> ring issued", t_issued - t_k0), ("entry -> ring issued", t_issued - t_entry), ("ring issued -> first k-tile landed", t_first - t_issued),
                 ("main loop", t_loop - t_first), ("accumulators -> LDS (+barrier)", t_lds - t_loop),
