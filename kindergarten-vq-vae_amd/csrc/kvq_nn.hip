@@ -1865,8 +1865,24 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
+// Diagnostic build only (-DKVQ_NN_DIAG, tools/build_diag.sh): every wave of the two 32-token attention kernels stores s_memtime at
+// entry, when its operand rows have landed, when its first store is issued and at its end: [workgroup][8] u64.
+#ifdef KVQ_NN_DIAG
+__device__ unsigned long long* g_nn_diag = nullptr;
+#define NN_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime();
+#define NN_DIAG_STORE(t0, t1, t2)                                                                     \
+    if (g_nn_diag != nullptr && threadIdx.x == 0) {                                                   \
+        unsigned long long* o = g_nn_diag + (size_t)blockIdx.x * 8;                                   \
+        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = __builtin_amdgcn_s_memrealtime(); \
+    }
+#else
+#define NN_T(var)
+#define NN_DIAG_STORE(t0, t1, t2)
+#endif
+
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned Vt[16 * AM_LDT];
+    NN_T(nn_t0)
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
     const bool kvalid = r < p.Sk, qvalid = r < p.Sq;
@@ -1890,6 +1906,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma32(kf[s], qf[s], acc);      // S^T[key][query]
     stage_pairs_from_chunks(Vt, r, h, vf);
+    NN_T(nn_t1)                                                       // (k, q, v rows have landed: the first MFMAs and the V staging consumed them)
     float s[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) s[v] = acc[v];
@@ -1900,6 +1917,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
     uint4 pf[2];
     acc_to_frags(s, pf);
     __syncthreads();
+    NN_T(nn_t2)                                                       // (softmax and dropout done: only P.V and the stores are left)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
         f32x16 o = zero16();
@@ -1908,6 +1926,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
         if (qvalid) store_ct(p.out, ((size_t)b * p.Sq + r) * p.ldo + hd * AT_D, h, 32 * dt, o);
     }
     if (qvalid && h == 0 && p.lse) p.lse[((size_t)b * p.nh + hd) * p.Sq + r] = lse;
+    NN_DIAG_STORE(nn_t0, nn_t1, nn_t2)
 }
 
 __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
@@ -1917,6 +1936,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned Xt[16 * AM_LDT];
     __shared__ __attribute__((aligned(16))) unsigned TD[AT_S * AM_LDX], TP[AT_S * AM_LDX];
     __shared__ __attribute__((aligned(16))) float Wv[3 * AT_S];
+    NN_T(nn_t0)
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
     const bool kvalid = r < p.Sk, qvalid = r < p.Sq;
@@ -1941,6 +1961,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) accP = mfma32(vf[s], gf[s], accP);     // dP~^T[key][query] = V[key] . dO[query]
     stage_pairs_from_chunks(Xt, r, h, kf);
+    NN_T(nn_t1)                                                       // (all four operand row sets have landed)
     float s[16], dp[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) { s[v] = accS[v]; dp[v] = accP[v]; }
@@ -1964,6 +1985,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     uint4 dsf[2];
     acc_to_frags(ds, dsf);
     __syncthreads();
+    NN_T(nn_t2)                                                       // (P, dS ready and staged: three products and the stores are left)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {                        // dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
         f32x16 o = zero16();
@@ -2020,6 +2042,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
         if (kvalid) store_ct(p.g_v, ((size_t)b * p.Sk + r) * p.ldv + hd * AT_D, h, 32 * dt, o);
     }
     if (partials && p.pb_v) p.pb_v[(size_t)b * p.ldp_kv + col] = weighted_colsum(Xt, Wv + 64, r, h);
+    NN_DIAG_STORE(nn_t0, nn_t1, nn_t2)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2321,6 +2344,12 @@ static int gelu_launch(const void* h, const void* g_a, void* out, int64_t n, int
 }
 
 extern "C" {
+
+#ifdef KVQ_NN_DIAG
+int kvq_nn_diag_set_buffer(void* buf) {       // diagnostic library only: [workgroups of the next attention launch][8] u64, or null
+    return hipMemcpyToSymbol(HIP_SYMBOL(kvq::g_nn_diag), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
                                 float eps, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* pre,
