@@ -303,6 +303,7 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
     // the 64-bit key the final atomicMin orders by anyway (monotone map of the distance, NaN lowest, then the code), and minima
     // are integer selects.  Same arithmetic for the distance (fl(fl(z2 + e2) - 2 acc)), same winner: key order == cand_better
     // order (-0 is canonicalised to +0 first; the two differ in nothing else).
+    if (PRIO) __builtin_amdgcn_s_setprio(3);                 // the tail ahead of the other workgroups' MFMA clusters: it frees the slot
     const float e2v = pe + __shfl_xor(pe, 32, WAVE);
     const int cbase = code0 + w * 32;
     float* e2s = smem + T2_WAVES * 2 * TMW + 32 * w;          // behind the merge buffers; 32 floats per wave (z stages are dead)
