@@ -11,6 +11,10 @@ Extra objects on the line:
   roofline     the VQ distance+argmin kernel (vq_dist_packed_kernel), timed with HIP events around every launch of the timed
                region on the stream it runs on; bound = f32 MFMA (exact-f32 distances), HBM figure beside it
   cpu_baseline oracle/step_oracle.py (CPU f32 restatement, "port") timed on this host's cores, rank 0 at N=1 only
+  clock_mhz    the shader clock held over the timed region (kvq_clock_probe stamps bracket it); roofline.frac_at_clock prices the
+               kernel against the peak at THAT clock, so lines from different boxes / rounds can be compared
+  families     kernel milliseconds per step by family (GEMM / attention / LayerNorm / loss / Adam / VQ ...), from event pairs around
+               every libkvq.so entry point of a few eager steps run after the timed region
 """
 import argparse
 import ctypes
@@ -48,6 +52,10 @@ def parse():
     ap.add_argument("--bucket-mib", type=int, default=64)
     ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4]: forward GEMMs on the fp8 matrix cores (backward bf16)")
     ap.add_argument("--factors", type=int, default=1, help="configs[4]: codebooks (MultiVectorQuantizer, K codes each); 1 = the reference's VectorQuantizer")
+    ap.add_argument("--bagon", action="store_true", help="the plain Bagon step (models/bagon/main.py: no quantiser) with the decoder's ids "
+                    "perturbed independently of the encoder's (models/bagon/Trainer.py:85,94); an extra line for profiles/, not the default")
+    ap.add_argument("--family-steps", type=int, default=2, help="eager steps after the timed region, event pairs around every entry "
+                    "point: kernel time per family (0 = skip)")
     ap.add_argument("--path", default="engine", choices=["engine", "autograd"],
                     help="engine = kvq.engine.TrainEngine (explicit fwd/bwd over flat buffers); autograd = kvq.bert + torch autograd")
     return ap.parse_args()
@@ -95,15 +103,22 @@ def main():
     torch.manual_seed(0)
     from models.bagon.Bagon import LOCAL_BERT_CONFIGS
     hidden = LOCAL_BERT_CONFIGS[a.model].get("hidden_size", 768)
-    if a.factors > 1:
-        from models.shelgon3.MultiVectorQuantizer import MultiVectorQuantizer
-        vq = MultiVectorQuantizer(n_factors=a.factors, n_e=a.codes, e_dim=hidden, beta=0.25)
+    vq = None
+    if a.bagon:
+        from models.bagon.Bagon import Bagon
+        if a.path != "engine":
+            raise SystemExit("--bagon is measured on the engine path")
+        model = Bagon(a.model, a.model, True, compute_dtype=dtype).to(dev)
     else:
-        vq = VectorQuantizer(n_e=a.codes, e_dim=hidden, beta=0.25)
-        vq.materialize_min_encodings = False
-    model = Shelgon(a.model, vq, a.model, None, compute_dtype=dtype).to(dev)
-    if model.encoder.config.hidden_size != vq.e_dim:
-        raise SystemExit("model hidden size must equal the codebook dimension")
+        if a.factors > 1:
+            from models.shelgon3.MultiVectorQuantizer import MultiVectorQuantizer
+            vq = MultiVectorQuantizer(n_factors=a.factors, n_e=a.codes, e_dim=hidden, beta=0.25)
+        else:
+            vq = VectorQuantizer(n_e=a.codes, e_dim=hidden, beta=0.25)
+            vq.materialize_min_encodings = False
+        model = Shelgon(a.model, vq, a.model, None, compute_dtype=dtype).to(dev)
+        if model.encoder.config.hidden_size != vq.e_dim:
+            raise SystemExit("model hidden size must equal the codebook dimension")
     model.set_mode(a.mode)
     model.train()                      # the reference trains with dropout on (Trainer.py:310)
     ddp.broadcast_parameters(model)
@@ -121,13 +136,23 @@ def main():
     # synthetic dSentences-like ids, resident in HBM before the timed region (BASELINE.md §3 recipe)
     gen = torch.Generator().manual_seed(69 + rank)
     pool = [tuple(t.to(dev) for t in random_token_batch(a.batch, a.seq_len, gen)) for _ in range(8)]
-    if engine is not None:
+    if a.bagon:
+        # decoder ids = the same sentences with 15 % of the tokens replaced independently (Trainer.py:94); resident in HBM as well
+        from common.tensor_utils import replace_pct_rand_values
+        torch.manual_seed(69 + rank)
+        pool = [(ids, mask, replace_pct_rand_values(ids, 0.15, 1000, 30000) * mask, mask) for ids, mask in pool]
+        pool = [(e, em, d, dm, engine.pack_batch(e, em, d, dm)) for e, em, d, dm in pool]
+    elif engine is not None:
         # a tokenised batch as the input pipeline hands it over (dsentences.token_cache): ids, mask and the ids' stable order
         # (what the word-embedding gradient needs) packed into one tensor, resident in HBM like the ids themselves
         pool = [(ids, mask, engine.pack_batch(ids, mask)) for ids, mask in pool]
 
     def one_step(i):
         ids, mask = pool[i % len(pool)][:2]
+        if a.bagon:
+            _, _, d, dm, pack = pool[i % len(pool)]
+            out = engine.train_step(ids, mask, prepared=pack, dec_ids=d, dec_mask=dm)
+            return out["loss_recon"], 0.0
         if engine is not None:
             out = engine.train_step(ids, mask, prepared=pool[i % len(pool)][2])
             return out["loss_recon"], out["loss_vq"]           # (added on the host after the timed region: no extra launch per step)
@@ -153,9 +178,12 @@ def main():
     if grouped:
         dist.barrier()
     torch.cuda.synchronize()
+    from kvq import nnops
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    probe0 = nnops.clock_probe()               # two single-wave-per-workgroup stamps bracket the K steps on their stream: the shader
+    for i in range(a.steps):                   # clock the chip HELD over the timed region (a few microseconds of the region itself)
         loss = one_step(a.warmup + i)
+    probe1 = nnops.clock_probe()
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
@@ -176,6 +204,32 @@ def main():
     vq_ms = sorted(buf[i] for i in range(n_ev))
     vq_avg_ms = sum(vq_ms) / max(len(vq_ms), 1) if vq_ms else float("nan")
 
+    clock_mhz, clock_per_xcd = nnops.clock_mhz(probe0, probe1)
+    # kernel time per family: a few EAGER steps after the timed region with an event pair around every entry point of libkvq.so
+    # (launches captured in a hipGraph cannot carry events); the empty-pair time is subtracted per launch
+    families = None
+    if engine is not None and a.family_steps > 0 and not grouped:
+        from kvq import _ffi as ffi
+        eng_graph = engine.use_graph
+        engine.use_graph = False
+        one_step(a.warmup + a.steps)                                       # settle into eager launches
+        torch.cuda.synchronize()
+        ffi.family_profile_begin()
+        fp0 = nnops.clock_probe()
+        for i in range(a.family_steps):
+            one_step(a.warmup + a.steps + 1 + i)
+        fp1 = nnops.clock_probe()
+        fam_ms, fam_n, empty_ms = ffi.family_profile_end()
+        engine.use_graph = eng_graph
+        families = {"ms_per_step": {k: v / a.family_steps for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])},
+                    "launches_per_step": {k: v / a.family_steps for k, v in fam_n.items()},
+                    "sum_ms_per_step": sum(fam_ms.values()) / a.family_steps, "empty_event_pair_us": empty_ms * 1e3,
+                    # these steps run with an event pair (a queue barrier) around every launch: the chip idles between kernels and
+                    # may hold another clock than in the timed region -- compare families across runs at THIS clock
+                    "clock_mhz": nnops.clock_mhz(fp0, fp1)[0],
+                    "method": f"{a.family_steps} eager steps after the timed region, HIP event pair around every libkvq.so entry point, "
+                              "empty-pair time subtracted"}
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,7 +237,9 @@ def main():
 
     if rank == 0:
         N_tok = a.batch * a.seq_len
-        D = vq.e_dim
+        D = vq.e_dim if vq is not None else hidden
+        CLOCK_NOMINAL_MHZ = 2400.0                     # the clock the MFMA peaks of MI355X_MICROARCH.md are quoted at
+        at_clock = (clock_mhz / CLOCK_NOMINAL_MHZ) if clock_mhz else None
         es = 2 if dtype == torch.bfloat16 else 4
         flops = 2.0 * N_tok * a.codes * D                                      # distance contraction
         alg_bytes = N_tok * (2 * D * es + 8) + a.codes * D * 4                  # read z, write z_q, write idx, codebook once
@@ -207,6 +263,8 @@ def main():
         H, Fi, S = ce.hidden_size, ce.intermediate_size, a.seq_len
         per_tok_enc = ce.num_hidden_layers * (2 * (4 * H * H + 2 * H * Fi) + 4 * S * H)
         per_tok_dec = cd.num_hidden_layers * (2 * (8 * H * H + 2 * H * Fi) + 8 * S * H) + 2 * H * H + 2 * H * cd.vocab_size
+        if vq is None:
+            flops = 0.0
         step_flops = 3.0 * N_tok * (per_tok_enc + per_tok_dec) + 3.0 * flops
         step_s = elapsed / a.steps
         out = {
@@ -217,27 +275,45 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("fp8 forward GEMMs / bf16" if a.fp8 else "bf16") if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": f"Bagon VQ (Shelgon) {a.model} enc/dec, {str(a.factors) + ' x ' if a.factors > 1 else ''}K={a.codes} D={D} "
-                                   f"seq_len={a.seq_len} batch={a.batch}/GPU, mode={a.mode}, Adam, dropout on, path={a.path}"
+            "config": {"workload": (f"Bagon (no quantiser, models/bagon/main.py) {a.model} enc/dec, decoder ids perturbed 15 % independently "
+                                    f"of the encoder's, " if a.bagon else
+                                    f"Bagon VQ (Shelgon) {a.model} enc/dec, {str(a.factors) + ' x ' if a.factors > 1 else ''}K={a.codes} D={D} ")
+                                   + f"seq_len={a.seq_len} batch={a.batch}/GPU, mode={a.mode}, Adam, dropout on, path={a.path}"
                                    + (", fp8 forward GEMMs" if a.fp8 else ""),
                        "global_batch": world * a.batch, "seq_len": a.seq_len, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
+            # ids + mask + the ids' stable order (what the word-embedding gradient is summed in) are built with the batch, before the
+            # timed region, as dsentences.token_cache hands them over in the training loop; the step starts from one device copy
+            "prepacked_batches": engine is not None,
+            # shader clock held over the timed region (kvq_clock_probe before the first and after the last step, same stream; median
+            # over the XCDs): the MFMA peaks are quoted at 2400 MHz, so achieved / (peak * clock_mhz / 2400) is the fraction of what
+            # the chip could deliver at the clock it actually ran
+            "clock_mhz": clock_mhz, "clock_mhz_per_xcd": clock_per_xcd, "clock_nominal_mhz": CLOCK_NOMINAL_MHZ,
+            "families": families,
             "graph": bool(engine is not None and engine._graphs),      # False = the step ran as ~800 eager launches (capture failed or off)
             "rccl_ranks": rccl_ranks, "dist_backend": (dist.get_backend() if grouped else None),
             "exposed_comm_ms_per_step": exposed_ms,
             # the whole step against the dense bf16 matrix-core peak (per GPU; a reading aid: `roofline` below is the contract's object)
             "step_mfma": {"flops_per_step": step_flops, "achieved": step_flops / step_s / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS,
-                          "unit": "TFLOP/s", "frac": step_flops / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS} if a.mode == "full" else None,
+                          "unit": "TFLOP/s", "frac": step_flops / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                          "frac_at_clock": (step_flops / step_s / 1e12 / (BF16_MFMA_PEAK_TFLOPS * at_clock)) if at_clock else None}
+            if a.mode == "full" else None,
             "roofline": {
                 "kernel": "vq_dist_packed_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": (ach_tflops / F32_MFMA_PEAK_TFLOPS) if ach_tflops else None,
-                "traffic": traffic, "avg_launch_us": vq_avg_ms * 1e3 if vq_ms else None, "launches": len(vq_ms),
+                "frac_at_clock": (ach_tflops / (F32_MFMA_PEAK_TFLOPS * at_clock)) if (ach_tflops and at_clock) else None,
+                "traffic": traffic, "traffic_source": "profiles/vq_fwd_traffic.json (rocprofv3 --pmc pass of this kernel, not this run)",
+                "avg_launch_us": vq_avg_ms * 1e3 if vq_ms else None, "launches": len(vq_ms),
                 "flops_per_launch": flops, "algorithmic_bytes_per_launch": dist_alg, "fabric_floor_bytes_per_launch": dist_floor,
                 "forward": {"algorithmic_bytes": alg_bytes, "traffic": sum(fwd_traffic.values()) if fwd_traffic else None,
                             "kernels": fwd_traffic},
                 "hbm": {"achieved": alg_bytes / (vq_avg_ms * 1e-3) / 1e9 if vq_ms else None, "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": alg_bytes / (vq_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if vq_ms else None},
-            },
+            } if vq is not None else {
+                # no quantiser in the plain Bagon step: the object describes the whole step against the bf16 matrix-core peak
+                "kernel": "whole step (MFMA GEMM family, csrc/kvq_gemm2.hip)", "bound": "mfma", "achieved": step_flops / step_s / 1e12,
+                "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_flops / step_s / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                "frac_at_clock": (step_flops / step_s / 1e12 / (BF16_MFMA_PEAK_TFLOPS * at_clock)) if at_clock else None, "traffic": None},
         }
         if world == 1 and not a.no_cpu_baseline:
             from oracle import step_oracle
@@ -247,12 +323,17 @@ def main():
                 cfg = dict(LOCAL_BERT_CONFIGS[a.model])
             cores = step_oracle.host_cores()
             print(f"[bench] timing the CPU restatement on {cores} host cores ...", file=sys.stderr, flush=True)
-            r = step_oracle.time_cpu_steps(cfg, batch=8, seq_len=a.seq_len, n_e=a.codes, e_dim=D, beta=0.25,
+            r = step_oracle.time_cpu_steps(cfg, batch=8, seq_len=a.seq_len, n_e=a.codes, e_dim=D, beta=0.25,  # (--bagon: same baseline)
                                            vocab_size=model.decoder.config.vocab_size, warmup=2, steps=a.cpu_steps,
                                            threads=cores, log=lambda m: print(m, file=sys.stderr, flush=True))
             out["cpu_baseline"] = {"value": r["sentences_per_s"], "unit": "sentences/s", "cores": r["threads"], "kind": "port",
                                    "sample": f"{r['steps']} timed steps (median) of oracle/step_oracle.py at batch=8 seq_len={a.seq_len} "
                                              f"f32 (BASELINE.json configs[0]), {r['s_per_step']:.2f} s/step"}
+            # BASELINE.md publishes no number for this metric; north_star's target is stated against the reference on the host's cores,
+            # so the ratio to the CPU restatement timed in this run stands in (different batch sizes: that is BASELINE.json's pairing)
+            out["vs_baseline"] = out["value"] / r["sentences_per_s"]
+            out["vs_baseline_note"] = (f"value / cpu_baseline.value: GPU step at batch {a.batch} bf16 vs CPU restatement at batch 8 f32 on "
+                                       f"{r['threads']} cores (BASELINE.json configs[1] vs configs[0]); north_star target >= 10")
         print(json.dumps(out), flush=True)
         # a line whose number means something else than it says is worse than no line: fail the run
         import math

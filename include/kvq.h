@@ -117,6 +117,13 @@ int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int 
 int kvq_prof_enable(int n_pairs);
 int kvq_prof_read(float* ms_host, int max);
 
+/* Clock probe (measurement aid of bench.py; no reference counterpart): every one of kvq_clock_probe_rows() single-wave workgroups
+ * stores out[row] = {XCC id, s_memtime, s_memrealtime, HW_ID} (4 x uint64).  Two probes on one stream bracket a region: per XCD,
+ * (memtime_1 - memtime_0) / (memrealtime_1 - memrealtime_0) x 100 MHz is the shader clock the chip held there (DVFS included);
+ * the peaks of MI355X_MICROARCH.md are quoted at 2.4 GHz.  Product kernels carry no stamps. */
+int kvq_clock_probe_rows(void);
+int kvq_clock_probe(uint64_t* out, size_t out_bytes, void* stream);
+
 /* Which path kvq_vq_forward takes for a shape: 1 = f32-MFMA LDS-tiled kernel, 0 = generic kernel. */
 int kvq_vq_uses_mfma(int64_t N, int K, int D);
 
@@ -140,6 +147,11 @@ int kvq_vq_ema_update(const void* z, const int64_t* idx, int64_t N, int K, int D
  */
 int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, int64_t ld, int io_dtype,
                    float* row_loss, float* row_lse, int64_t* pred, float* loss, float* acc, void* stream);
+
+/* seq_acc's per-sentence result (common/metrics.py:32-36; consumed as stats_step["metric_acc_step_per_sentence"] by
+ * models/bagon/Trainer.py:107,275): per_sentence[b] = mean over s of (pred[b,s] == target[b,s]); pred / target [B,S] int64 row-major
+ * (pred = kvq_ce_forward's arg-max).  The per-batch value is kvq_ce_forward's `acc`. */
+int kvq_seq_acc(const int64_t* pred, const int64_t* target, int64_t B, int S, float* per_sentence, void* stream);
 
 /* The same results from the per-tile statistics of kvq_gemm_bf16_ce (below): stats [N][tiles][4] f32 = (max, sum exp(x - max),
  * first arg-max as int bits, unused) of row n over tile t's columns < V.  Reads ONE logit per row (the target's); the [N, V]

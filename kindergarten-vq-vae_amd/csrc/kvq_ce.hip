@@ -144,6 +144,19 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restric
     }
 }
 
+// seq_acc's second result (common/metrics.py:32-36): per_sentence[b] = mean_s(pred[b, s] == target[b, s]).  One wave per sentence.
+__global__ __launch_bounds__(256) void seq_acc_kernel(const int64_t* __restrict__ pred, const int64_t* __restrict__ target, int64_t B,
+                                                       int S, float* __restrict__ per_sentence) {
+    const int64_t b = (int64_t)blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    int hits = 0;
+    for (int s = lane; s < S; s += WAVE) hits += pred[b * S + s] == target[b * S + s];
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) hits += __shfl_xor(hits, mk, WAVE);
+    if (lane == 0) per_sentence[b] = (float)hits / (float)S;
+}
+
 // The same row results from per-tile statistics left by the LM-head GEMM's epilogue (kvq_gemm_bf16_ce): stats [N][tiles][4] =
 // (max, sum of exp(x - max), first arg-max as int bits, -) of row n over the columns of tile t below V.  One thread per row merges
 // the tiles in column order (so the first maximum wins) and reads ONE logit, the target's: the [N, V] logits are not read again.
@@ -283,6 +296,13 @@ int kvq_ce_forward(const void* logits, const int64_t* target, int64_t N, int V, 
         rc = check_launch("ce_finalize_kernel");
     }
     return rc;
+}
+
+int kvq_seq_acc(const int64_t* pred, const int64_t* target, int64_t B, int S, float* per_sentence, void* stream) {
+    KVQ_REQUIRE(pred && target && per_sentence, "kvq_seq_acc: null pointer argument");
+    KVQ_REQUIRE(B > 0 && S > 0 && B < (1ll << 31), "kvq_seq_acc: B=%lld S=%d out of range", (long long)B, S);
+    hipLaunchKernelGGL(seq_acc_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pred, target, B, S, per_sentence);
+    return check_launch("seq_acc_kernel");
 }
 
 int kvq_ce_forward_stats(const void* logits, const int64_t* target, int64_t N, int64_t ld, int io_dtype, const float* stats, int tiles,

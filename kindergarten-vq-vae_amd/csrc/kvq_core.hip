@@ -35,9 +35,33 @@ void prof_end(hipStream_t st) {
     ++g_count;
 }
 
+// ---- clock probe ----------------------------------------------------------------------------------------------
+// One wave per workgroup stores {XCC id, s_memtime (shader-clock cycles), s_memrealtime (constant 100 MHz), hardware id}.  Two
+// probes on one stream bracket a region; per XCD (the cycle counter is the XCD's own) d(memtime) / d(memrealtime) x 100 MHz is
+// the shader clock the chip HELD over the region, DVFS included.  No product kernel carries a stamp (MI355X_MICROARCH.md, DVFS (6)).
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 0xf;
+    const unsigned hwid = __builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((32 - 1) << 11));
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* o = out + (size_t)blockIdx.x * 4;
+    o[0] = xcc; o[1] = t; o[2] = r; o[3] = hwid;
+}
+
 }  // namespace kvq
 
 extern "C" {
+
+int kvq_clock_probe_rows(void) { return 64; }
+
+int kvq_clock_probe(uint64_t* out, size_t out_bytes, void* stream) {
+    using namespace kvq;
+    KVQ_REQUIRE(out, "kvq_clock_probe: null pointer argument");
+    if (out_bytes < (size_t)64 * 4 * sizeof(uint64_t)) return fail(KVQ_E_WORKSPACE, "kvq_clock_probe: %zu bytes < %zu", out_bytes, (size_t)64 * 32);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(out));
+    return check_launch("clock_probe_kernel");
+}
 
 int kvq_prof_enable(int n_pairs) {
     using namespace kvq;

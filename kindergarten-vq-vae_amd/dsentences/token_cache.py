@@ -14,7 +14,7 @@ import torch
 
 class TokenCache:
     def __init__(self, sentences: Sequence[str], tokenizer, max_length: int, add_special_tokens: bool = False,
-                 device="cpu", chunk: int = 16384):
+                 device="cpu", chunk: int = 16384, labels: Optional[torch.Tensor] = None):
         parts = []
         for i in range(0, len(sentences), chunk):
             tok = tokenizer(list(sentences[i:i + chunk]), return_tensors="pt", padding="max_length", max_length=max_length,
@@ -27,6 +27,11 @@ class TokenCache:
         self.input_ids = ids.to(device)                               # [M, L], stays on the device
         self.attention_mask = (self.input_ids != self.pad_id).to(torch.int64)
         self.device = self.input_ids.device
+        # the id the "packed" sort files under -1 = the padding_idx of the MODEL's word embeddings (its row receives no gradient,
+        # modeling_bert.py:60), which need not be the tokenizer's pad id: the entry points set it from TrainEngine.pad_idx
+        # (None = the model has no padding row: nothing is filed away; "off" = batches carry no "packed" entry)
+        self.packed_pad_id = self.pad_id
+        self.labels = labels.to(self.device) if labels is not None else None       # latent class labels [M, F], handed out per batch
 
     def __len__(self) -> int:
         return int(self.input_ids.shape[0])
@@ -38,9 +43,12 @@ class TokenCache:
         index = index.to(self.device)
         ids, mask = self.input_ids.index_select(0, index), self.attention_mask.index_select(0, index)
         out = {"input_ids": ids, "attention_mask": mask}
-        if ids.is_cuda:
+        if self.labels is not None:
+            out["latent_classes_labels"] = self.labels.index_select(0, index)
+        if ids.is_cuda and self.packed_pad_id != "off":
             flat = ids.reshape(-1)
-            srt, perm = torch.sort(torch.where(flat == self.pad_id, torch.full_like(flat, -1), flat), stable=True)
+            key = flat if self.packed_pad_id is None else torch.where(flat == self.packed_pad_id, torch.full_like(flat, -1), flat)
+            srt, perm = torch.sort(key, stable=True)
             out["packed"] = torch.stack([flat, mask.reshape(-1), srt, perm])
         return out
 
@@ -80,12 +88,21 @@ class TokenCacheLoader:
             yield self.cache.batch(mine[i * self.batch_size:(i + 1) * self.batch_size])
 
 
-def cache_of_split(split, tokenizer, max_length: int, add_special_tokens: bool, device) -> TokenCache:
-    """TokenCache of a torch.utils.data.Subset / dataset whose items carry a "sentence" (random_split output of the mains)."""
+def cache_of_split(split, tokenizer, max_length: int, add_special_tokens: bool, device, keep_labels: bool = False) -> TokenCache:
+    """TokenCache of a torch.utils.data.Subset / dataset whose items carry a "sentence" (random_split output of the mains).
+    keep_labels: batches also carry the split's "latent_classes_labels" (the Bagon trainer's decode step reads them)."""
+    labels = None
     if hasattr(split, "dataset") and hasattr(split, "indices") and hasattr(split.dataset, "sentences"):
         sentences = [split.dataset.sentences[i] for i in split.indices]
+        if keep_labels and getattr(split.dataset, "latent_classes_labels", None) is not None:
+            labels = split.dataset.latent_classes_labels[torch.as_tensor(list(split.indices), dtype=torch.int64)]
     elif hasattr(split, "sentences"):
         sentences = list(split.sentences)
+        if keep_labels:
+            labels = getattr(split, "latent_classes_labels", None)
     else:
-        sentences = [split[i]["sentence"] for i in range(len(split))]
-    return TokenCache(sentences, tokenizer, max_length, add_special_tokens, device)
+        items = [split[i] for i in range(len(split))]
+        sentences = [it["sentence"] for it in items]
+        if keep_labels and items and "latent_classes_labels" in items[0]:
+            labels = torch.stack([it["latent_classes_labels"] for it in items])
+    return TokenCache(sentences, tokenizer, max_length, add_special_tokens, device, labels=labels)

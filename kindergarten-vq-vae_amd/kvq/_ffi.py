@@ -42,6 +42,8 @@ SIGNATURES = {
     "kvq_device_info": (_int, [C.POINTER(_int), C.c_char_p, _sz]),
     "kvq_prof_enable": (_int, [_int]),
     "kvq_prof_read": (_int, [C.POINTER(C.c_float), _int]),
+    "kvq_clock_probe_rows": (_int, []),
+    "kvq_clock_probe": (_int, [_vp, _sz, _vp]),
     "kvq_vq_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "kvq_vq_uses_mfma": (_int, [_i64, _int, _int]),
     "kvq_vq_forward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -56,6 +58,7 @@ SIGNATURES = {
     "kvq_gumbel_forward": (_int, [_vp, _vp, _i64, _int, _f32, _int, C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp]),
     "kvq_gumbel_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, _int, _vp, _vp]),
     "kvq_ce_forward": (_int, [_vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kvq_seq_acc": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "kvq_ce_backward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp]),
     "kvq_ce_bwd_partial_rows": (_i64, [_i64]),
     "kvq_ce_backward_bias": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _sz, _vp]),
@@ -141,7 +144,69 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
-    return _lib
+    return _lib if _fam is None else _FamilyProxy(_lib)
+
+
+# ---- per-family kernel time (bench.py): event pairs around every entry point of a few EAGER steps -------------------------------
+_FAMILIES = (("kvq_gemm_", "gemm"), ("kvq_attn_", "attention"), ("kvq_dropout_residual_ln", "layernorm"), ("kvq_ln_", "layernorm"),
+             ("kvq_embed_ln_fwd", "layernorm"), ("kvq_ce_", "loss"), ("kvq_seq_acc", "loss"), ("kvq_adam_", "adam"),
+             ("kvq_step_state_", "adam"), ("kvq_vq_", "vq"), ("kvq_gumbel_", "vq"), ("kvq_fp8_", "fp8_quantize"), ("kvq_reduce_batch", "reduce"),
+             ("kvq_colsum", "reduce"), ("kvq_sum_slabs", "reduce"), ("kvq_gelu_", "gelu"), ("kvq_embed_grad", "embedding_grad"),
+             ("kvq_zero_ranges", "embedding_grad"))
+_fam = None          # None = off; else dict(events=[(family, e0, e1)], cal=[(e0, e1)])
+
+
+class _FamilyProxy:
+    """Stands in for the CDLL while family_profile_begin() is active: every entry point that launches on a stream (last argument:
+    the stream) runs between two events of the current torch stream, filed under its kernel family."""
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        sig = SIGNATURES.get(name)
+        if _fam is None or sig is None or not sig[1] or sig[1][-1] is not _vp or name.endswith(("_bytes", "_rows")) \
+                or name in ("kvq_set_seed_offset", "kvq_clock_probe"):
+            return fn
+        family = next((f for pre, f in _FAMILIES if name.startswith(pre)), "other")
+
+        def call(*args):
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            _fam["events"].append((family, e0, e1))
+            return rc
+        return call
+
+
+def family_profile_begin():
+    """From now on lib() hands out the timing proxy.  Run EAGER steps (no hipGraph replay: captured launches cannot carry events)."""
+    global _fam
+    import torch
+    lib()
+    _fam = dict(events=[], cal=[])
+    for _ in range(32):                       # what an EMPTY pair measures: subtracted per launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()
+        _fam["cal"].append((e0, e1))
+
+
+def family_profile_end():
+    """Stop; returns ({family: ms summed over the launches seen}, {family: launches}, ms of an empty event pair).  Synchronises."""
+    global _fam
+    import torch
+    torch.cuda.synchronize()
+    rec, _fam = _fam, None
+    cal = sorted(e0.elapsed_time(e1) for e0, e1 in rec["cal"])
+    empty = cal[len(cal) // 2] if cal else 0.0
+    ms, n = {}, {}
+    for family, e0, e1 in rec["events"]:
+        ms[family] = ms.get(family, 0.0) + max(e0.elapsed_time(e1) - empty, 0.0)
+        n[family] = n.get(family, 0) + 1
+    return ms, n, empty
 
 
 def check(rc: int, what: str):

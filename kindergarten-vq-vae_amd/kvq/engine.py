@@ -234,14 +234,15 @@ class _StepGraphs:
     Replay = graph, interlude, graph, ...: ~3 host launches per step on one GPU instead of ~800.  Nothing inside the graphs
     depends on host values that change between steps: see the device step state in include/kvq.h."""
 
-    def __init__(self, eng, ids, mask):
+    def __init__(self, eng, ids, mask, dec=None):
         self.eng = eng
         dev = eng.dev
         # static input buffers the captured kernels read: ids | mask | ids sorted (stable, pads under -1) | their order
-        self.pack = eng.pack_batch(ids, mask)
-        self.ids, self.mask = self.pack[0].view(ids.shape), self.pack[1].view(ids.shape)
-        self.sorted = (self.pack[2], self.pack[3])
+        # [| the decoder's own ids | mask | sorted | order | the loss target -- a Bagon step, models/bagon/Trainer.py:65-130]
+        self.pack = eng.pack_batch(ids, mask, *(dec or ())).reshape(-1)
         N, H = ids.numel(), eng.H
+        self.ids, self.mask, srt, perm, self.dec = eng.unpack_batch(self.pack, ids.shape, dec[0].shape if dec else None)
+        self.sorted = (srt, perm)
         self.z_q = torch.empty((N, H), dtype=eng.dtype, device=dev)
         self.idx = torch.empty(N * max(eng.G, 1), dtype=torch.int64, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float32, device=dev)         # loss, accuracy | quantiser loss, perplexity: one clone per step
@@ -258,8 +259,10 @@ class _StepGraphs:
                 # thread-local capture mode: the process group's helper threads (gloo copies, the RCCL watchdog's event queries)
                 # keep issuing HIP calls on their own streams while this thread captures
                 self.graphs[0].capture_begin(capture_error_mode="thread_local")
-                eng._prepared = self.sorted
-                self.out = eng.forward_backward(self.ids, self.mask, training=eng.model.training, compute_grads=True, fuse_optimizer=True)
+                eng._prepared = dict(enc=self.sorted, dec=self.dec[2:4] if self.dec else None)
+                dkw = dict(dec_ids=self.dec[0], dec_mask=self.dec[1], target_ids=self.dec[4]) if self.dec else {}
+                self.out = eng.forward_backward(self.ids, self.mask, training=eng.model.training, compute_grads=True, fuse_optimizer=True,
+                                                **dkw)
                 eng.optimizer_step()
                 self.graphs[-1].capture_end()
                 ok = True
@@ -285,15 +288,24 @@ class _StepGraphs:
         g.capture_begin(pool=self.graphs[0].pool(), capture_error_mode="thread_local")
         self.graphs.append(g)
 
-    def run(self, ids, mask, prepared=None):
-        if prepared is not None and prepared.shape == self.pack.shape:
-            self.pack.copy_(prepared)               # a batch packed where it was built (TrainEngine.pack_batch): one copy
+    def run(self, ids, mask, prep, dec=None):
+        """prep: TrainEngine._normalise_prepared()'s dict (pack = the whole batch as one tensor, or the sorted ids of either side)."""
+        if prep["pack"] is not None:
+            self.pack.copy_(prep["pack"])           # a batch packed where it was built (TrainEngine.pack_batch): one copy
         else:                                       # otherwise the sort happens here -- outside the graphs, but in the step
             self.ids.copy_(ids)
             self.mask.copy_(mask)
-            srt, perm = self.eng.prepare_batch(ids)
+            srt, perm = prep["enc"] if prep["enc"] is not None else self.eng.prepare_batch(ids)
             self.sorted[0].copy_(srt)
             self.sorted[1].copy_(perm)
+            if self.dec:
+                d_ids, d_mask, tgt = dec
+                self.dec[0].copy_(d_ids)
+                self.dec[1].copy_(d_mask)
+                srt, perm = prep["dec"] if prep["dec"] is not None else self.eng.prepare_batch(d_ids)
+                self.dec[2].copy_(srt)
+                self.dec[3].copy_(perm)
+                self.dec[4].copy_(d_ids if tgt is None else tgt)
         for i, g in enumerate(self.graphs):
             g.replay()
             if i < len(self.inter):
@@ -325,6 +337,7 @@ class TrainEngine:
         self.dtype = model.compute_dtype
         self.io = 1 if self.dtype == torch.bfloat16 else 0
         self.has_vq = hasattr(model, "vector_quantizer")
+        self.sentence_acc = not self.has_vq       # the plain Bagon step reports the accuracy of every sentence as well
         self.vq_kind = type(model.vector_quantizer).__name__ if self.has_vq else None
         if self.has_vq and self.vq_kind not in _QUANTIZERS:
             raise KvqError(f"TrainEngine schedules {', '.join(_QUANTIZERS)}; got {self.vq_kind}")
@@ -521,6 +534,11 @@ class TrainEngine:
 
     def __reduce__(self):
         return (type(None), ())       # torch.save(model): the engine (streams, graphs, flat mirrors) is not part of a checkpoint
+
+    @property
+    def pad_idx(self):
+        """padding_idx of the word embeddings (None = no padding row): the id a packed batch files under -1 (prepare_batch)."""
+        return self._pad_idx
 
     @property
     def step_count(self):
@@ -832,8 +850,13 @@ class TrainEngine:
             if g_y.shape[1] % 4 == 0 and g_y.shape[1] <= 1024:
                 # deterministic segmented sum over the tokens sorted by id: the order is a property of the BATCH, prepared once
                 # where the batch is built (prepare_batch: dsentences.token_cache / the trainer), not inside the replayed step
-                if self._sorted_ids is None:
-                    self._sorted_ids = self.prepare_batch(ids)
+                srt = self._sorted[prefix]
+                if isinstance(srt, str):                  # the decoder reads the encoder's ids: one sort serves both tables
+                    if self._sorted[srt] is None:
+                        self._sorted[srt] = self.prepare_batch(ids)
+                    srt = self._sorted[srt]
+                elif srt is None:
+                    srt = self._sorted[prefix] = self.prepare_batch(ids)
                 # the tables are zeroed by ONE launch (word unless it accumulates into the LM-head gradient, position, token type)
                 zero = [None if tied_accumulate else gw, fl.g(prefix + "pos") if tr[prefix + "pos"] else None,
                         fl.g(prefix + "type") if tr[prefix + "type"] else None]
@@ -842,7 +865,7 @@ class TrainEngine:
                     zeroed = True
                 elif not tied_accumulate:
                     gw.zero_()
-                nnops.embed_grad(g_y, self._sorted_ids[1], self._sorted_ids[0], gw, accumulate=tied_accumulate)
+                nnops.embed_grad(g_y, srt[1], srt[0], gw, accumulate=tied_accumulate)
             else:
                 acc = torch.zeros(shape, dtype=torch.float32, device=self.dev)
                 acc.index_add_(0, ids.reshape(-1), g_y.float())
@@ -1073,9 +1096,12 @@ class TrainEngine:
     # ------------------------------------------------------------------------------------------------------------
     def forward_backward(self, input_ids, attention_mask, training=True, compute_grads=True, dec_ids=None, dec_mask=None,
                          want_logits=False, quantizer_training=None, fuse_optimizer=False, stop_after_quantizer=False,
-                         defer_backward=False):
-        """Forward (+ backward when compute_grads).  Returns dict(loss_recon, loss_vq, perplexity, acc, recon_ids, indices
-        [, logits]).  dec_ids / dec_mask: the decoder's own input (Bagon.forward takes one; default = the encoder's).
+                         defer_backward=False, target_ids=None):
+        """Forward (+ backward when compute_grads).  Returns dict(loss_recon, loss_vq, perplexity, acc, acc_per_sentence,
+        recon_ids, indices [, logits]).  dec_ids / dec_mask: the decoder's own input (Bagon.forward takes one, and the Bagon step
+        tokenises and perturbs the two sides separately, models/bagon/Trainer.py:78-96; default = the encoder's).  target_ids:
+        what the loss and the accuracy score the logits against (default = the decoder's input, as models/bagon/Trainer.py:103-110
+        and models/shelgon3/Trainer.py:94-101 do).
         fuse_optimizer (train_step only; optimizer_step() MUST follow): parameters are updated while backward still runs.
         defer_backward (with compute_grads=False): the forward's activations stay alive and out["_resume"] can be handed to
         backward_from() once the gradient of the returned logits is known (kvq.engine.engine_autograd_forward)."""
@@ -1086,15 +1112,17 @@ class TrainEngine:
         if S > (128 if self.dtype == torch.bfloat16 else 32):
             raise KvqError(f"TrainEngine: sequence length {S} above the attention kernels' limit (32 tokens in f32, 128 in bf16 "
                            f"through the blocked kernels; use the autograd path)")
-        if (compute_grads or defer_backward) and dec_ids is not None:
-            raise KvqError("TrainEngine: the backward schedule covers the autoencoding step (decoder input = encoder input)")
+        if dec_ids is not None and (dec_mask is None or dec_ids.shape[0] != input_ids.shape[0] or dec_mask.shape != dec_ids.shape):
+            raise KvqError("TrainEngine: dec_ids needs a dec_mask of its shape and the encoder's batch size")
+        if target_ids is not None and target_ids.shape != (dec_ids if dec_ids is not None else input_ids).shape:
+            raise KvqError("TrainEngine: target_ids must have the shape of the decoder's input")
         if defer_backward and (compute_grads or self._cap is not None or self._dp):
             raise KvqError("TrainEngine: defer_backward is a single-process, eager, forward-first call")
         self._site_ctr = 0
         self._red_items, self._red_keep = [], []
         self._wg_items, self._wg_keep = [], []
-        pre = getattr(self, "_prepared", None)                  # this batch's (sorted ids, order) -- or its pack_batch() tensor
-        self._sorted_ids = (pre[2], pre[3]) if torch.is_tensor(pre) else pre
+        pre = getattr(self, "_prepared", None) or {}            # this batch's (sorted ids, order) per side: _normalise_prepared()
+        self._sorted = {"enc.emb.": pre.get("enc"), "dec.emb.": pre.get("dec") if dec_ids is not None else "enc.emb."}
         nnops.set_seed_offset(self._state)        # dropout seeds of this engine's launches = _step_seed + device step count
         try:
             self._q_training = training if quantizer_training is None else bool(quantizer_training)
@@ -1102,9 +1130,9 @@ class TrainEngine:
                 if self.fp8:
                     self._a8_site = 0
                 out = self._forward_backward(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits,
-                                             defer=bool(defer_backward))
+                                             defer=bool(defer_backward), target_ids=target_ids)
                 if defer_backward:
-                    out["_resume"] = dict(gen=out.pop("_gen"), sorted_ids=self._sorted_ids, step=self._step_host,
+                    out["_resume"] = dict(gen=out.pop("_gen"), sorted_ids=self._sorted, step=self._step_host,
                                           versions=self._versions())
                 if self.fp8 and compute_grads:
                     # the next TRAINING step's activation scales from this step's amax (4x headroom).  A forward-only call
@@ -1137,8 +1165,8 @@ class TrainEngine:
                                      stop_after_quantizer=True)
 
     def _forward_backward(self, input_ids, attention_mask, training, compute_grads, dec_ids=None, dec_mask=None, want_logits=False,
-                          defer=False):
-        gen = self._fb_gen(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits, defer)
+                          defer=False, target_ids=None):
+        gen = self._fb_gen(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits, defer, target_ids)
         try:
             out = next(gen)                 # only a deferred call yields: forward done, the generator holds the activations
         except StopIteration as done:
@@ -1157,7 +1185,7 @@ class TrainEngine:
         resume["done"] = True
         self._red_items, self._red_keep = [], []
         self._wg_items, self._wg_keep = [], []
-        self._sorted_ids = resume["sorted_ids"]
+        self._sorted = resume["sorted_ids"]
         self._fuse_opt = False
         self._g_vq_ext = (g_loss_vq.detach().to(torch.float32).reshape(()) if g_loss_vq is not None
                           else torch.zeros((), dtype=torch.float32, device=self.dev)) if self.has_vq else None
@@ -1187,7 +1215,7 @@ class TrainEngine:
                 out[a["p"]] = torch.empty_like(a["p"]).copy_(a["g"].reshape(a["p"].shape))
         return out
 
-    def _fb_gen(self, input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits, defer):
+    def _fb_gen(self, input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits, defer, target_ids=None):
         m = self.model
         fl, H = self.flat, self.H
         B, S = input_ids.shape
@@ -1246,7 +1274,7 @@ class TrainEngine:
         hN, hpre, hmean, hrstd = nnops.ln_fwd(ta, None, fl.w32("head.ln.w"), fl.w32("head.ln.b"), dcfg.layer_norm_eps)
         Wv = fl.w("dec.emb.word", rows=self.Vp)                              # [Vp,H], rows >= V are zero
         bv = fl.shadow[fl.seg["head.bias"][0]: fl.seg["head.bias"][0] + self.Vp]
-        tgt = d_ids.reshape(-1)
+        tgt = (d_ids if target_ids is None else target_ids).reshape(-1)
         # LM head; with the own kernel its epilogue also leaves the loss' forward statistics per (row, 256-column tile): the
         # [N, Vp] logits are then read by the loss only once more, in backward (opt-in, KVQ_OWN_LMCE=1; default: library GEMM + kvq_ce_forward)
         lm_stats = None
@@ -1265,9 +1293,13 @@ class TrainEngine:
             check(lib().kvq_ce_forward(logits.data_ptr(), tgt.data_ptr(), Nd, self.V, self.Vp, self.io, row_loss.data_ptr(),
                                        row_lse.data_ptr(), pred.data_ptr(), ce_out[0:].data_ptr(), ce_out[1:].data_ptr(), stream_ptr()),
                   "kvq_ce_forward")
+        acc_sent = None
+        if self.sentence_acc:               # seq_acc's second result (common/metrics.py:32-36), read by the Bagon trainer's decode step
+            acc_sent = torch.empty(B, dtype=torch.float32, device=self.dev)
+            check(lib().kvq_seq_acc(pred.data_ptr(), tgt.data_ptr(), B, Sd, acc_sent.data_ptr(), stream_ptr()), "kvq_seq_acc")
         out = dict(loss_recon=ce_out[0] if self.w_recon == 1.0 else ce_out[0] * self.w_recon,
                    loss_vq=(loss_vq if self.w_vq == 1.0 else loss_vq * self.w_vq) if self.has_vq else None,
-                   perplexity=perplexity, acc=ce_out[1], recon_ids=pred.view(B, Sd), indices=indices)
+                   perplexity=perplexity, acc=ce_out[1], acc_per_sentence=acc_sent, recon_ids=pred.view(B, Sd), indices=indices)
         if want_logits:
             out["logits"] = logits[:, :self.V].reshape(B, Sd, self.V)
             out["loss_vq_raw"] = loss_vq                          # without the trainer's loss weight
@@ -1291,14 +1323,14 @@ class TrainEngine:
                 self._defer_colsum(g_logits, fl.g("head.bias", rows=self.Vp))
         elif tr["head.bias"] and self.Vp % 8 == 0:
             # in place: logits := d loss / d logits; the LM-head bias gradient leaves the same pass as partial column sums
-            pb = torch.empty((lib().kvq_ce_bwd_partial_rows(N), self.Vp), dtype=torch.float32, device=self.dev)
-            check(lib().kvq_ce_backward_bias(logits.data_ptr(), tgt.data_ptr(), row_lse.data_ptr(), g_scale.data_ptr(), N, self.V,
+            pb = torch.empty((lib().kvq_ce_bwd_partial_rows(Nd), self.Vp), dtype=torch.float32, device=self.dev)
+            check(lib().kvq_ce_backward_bias(logits.data_ptr(), tgt.data_ptr(), row_lse.data_ptr(), g_scale.data_ptr(), Nd, self.V,
                                              self.Vp, self.io, logits.data_ptr(), pb.data_ptr(), pb.numel() * 4, stream_ptr()),
                   "kvq_ce_backward_bias")
             self._defer(pb, fl.g("head.bias", rows=self.Vp), pb.shape[0], self.Vp, self.Vp)
             g_logits = logits
         else:
-            check(lib().kvq_ce_backward(logits.data_ptr(), tgt.data_ptr(), row_lse.data_ptr(), g_scale.data_ptr(), N, self.V, self.Vp,
+            check(lib().kvq_ce_backward(logits.data_ptr(), tgt.data_ptr(), row_lse.data_ptr(), g_scale.data_ptr(), Nd, self.V, self.Vp,
                                         self.io, logits.data_ptr(), stream_ptr()), "kvq_ce_backward")      # in place
             g_logits = logits
             if tr["head.bias"]:
@@ -1619,42 +1651,110 @@ class TrainEngine:
         srt, perm = torch.sort(flat_ids, stable=True)
         return srt, perm
 
-    def pack_batch(self, input_ids, attention_mask):
-        """ids | mask | sorted ids | order as ONE int64 tensor [4, B*S]: a replayed step then starts with one device copy."""
+    def pack_batch(self, input_ids, attention_mask, dec_ids=None, dec_mask=None, target_ids=None):
+        """ids | mask | sorted ids | order as ONE int64 tensor [4, B*S]: a replayed step then starts with one device copy.
+        With the decoder's own input (a Bagon step): one flat tensor of 4*B*S + 5*B*Sd entries, the same four rows followed by
+        the decoder's ids | mask | sorted ids | order | loss target (= the decoder ids unless target_ids is given)."""
         srt, perm = self.prepare_batch(input_ids)
-        return torch.stack([input_ids.reshape(-1), attention_mask.reshape(-1).to(torch.int64), srt, perm])
+        rows = [input_ids.reshape(-1), attention_mask.reshape(-1).to(torch.int64), srt, perm]
+        if dec_ids is None:
+            if dec_mask is not None or target_ids is not None:
+                raise KvqError("TrainEngine.pack_batch: dec_mask / target_ids without dec_ids")
+            return torch.stack(rows)
+        dsrt, dperm = self.prepare_batch(dec_ids)
+        rows += [dec_ids.reshape(-1), dec_mask.reshape(-1).to(torch.int64), dsrt, dperm,
+                 (dec_ids if target_ids is None else target_ids).reshape(-1)]
+        return torch.cat(rows)
 
-    def _train_step_eager(self, input_ids, attention_mask, prepared=None):
-        self._prepared = prepared
+    @staticmethod
+    def unpack_batch(pack, enc_shape, dec_shape=None):
+        """Views into a pack_batch() tensor: (ids, mask, sorted ids, order, None | (dec ids, dec mask, sorted, order, target))."""
+        flat = pack.reshape(-1)
+        N = enc_shape[0] * enc_shape[1]
+        Nd = dec_shape[0] * dec_shape[1] if dec_shape is not None else 0
+        if flat.numel() != 4 * N + 5 * Nd or flat.dtype != torch.int64:
+            raise KvqError(f"TrainEngine: a packed batch of {flat.numel()} {flat.dtype} entries does not fit ids {tuple(enc_shape)}"
+                           + (f" + decoder ids {tuple(dec_shape)}" if dec_shape is not None else "")
+                           + " (pack_batch() of the same call's ids)")
+        r = [flat[i * N:(i + 1) * N] for i in range(4)]
+        dec = None
+        if dec_shape is not None:
+            d = [flat[4 * N + i * Nd: 4 * N + (i + 1) * Nd] for i in range(5)]
+            dec = (d[0].view(dec_shape), d[1].view(dec_shape), d[2], d[3], d[4].view(dec_shape))
+        return r[0].view(enc_shape), r[1].view(enc_shape), r[2], r[3], dec
+
+    def _normalise_prepared(self, prepared, input_ids, dec_ids=None, check_ids=False):
+        """`prepared` of train_step() in one form: dict(pack = the whole batch as pack_batch() laid it out | None,
+        enc = (sorted ids, order) | None, dec = likewise for the decoder's ids).  Accepted: None; prepare_batch()'s tuple (the
+        encoder side); a dict(enc=tuple, dec=tuple); a pack_batch() tensor.  A pack is authoritative: the step reads ids, masks
+        and target from it (eagerly and on replay alike); check_ids compares them with the ids of the call (a device sync:
+        done on the first, eager steps of a batch shape)."""
+        none = dict(pack=None, enc=None, dec=None)
+        if prepared is None:
+            return none
+        if isinstance(prepared, dict):
+            return dict(none, **{k: prepared.get(k) for k in ("enc", "dec")})
+        if isinstance(prepared, (tuple, list)):
+            if len(prepared) != 2 or any(not torch.is_tensor(t) or t.numel() != input_ids.numel() for t in prepared):
+                raise KvqError("TrainEngine: prepared=(sorted ids, order) must be prepare_batch() of this call's input_ids")
+            return dict(none, enc=(prepared[0].reshape(-1), prepared[1].reshape(-1)))
+        if not torch.is_tensor(prepared):
+            raise KvqError(f"TrainEngine: prepared must be pack_batch()'s tensor or prepare_batch()'s tuple, got {type(prepared).__name__}")
+        ids, mask, srt, perm, dec = self.unpack_batch(prepared, input_ids.shape, dec_ids.shape if dec_ids is not None else None)
+        if check_ids and not (torch.equal(ids, input_ids) and (dec is None or torch.equal(dec[0], dec_ids))):
+            raise KvqError("TrainEngine: the packed batch holds other ids than the ones passed to train_step()")
+        return dict(pack=prepared.reshape(-1), enc=(srt, perm), dec=dec[2:4] if dec is not None else None, views=(ids, mask, dec))
+
+    def _train_step_eager(self, input_ids, attention_mask, prep, dec=None):
+        if prep["pack"] is not None:              # the pack is what a replayed step reads: the eager step reads the same tensors
+            input_ids, attention_mask, dv = prep["views"]
+            dec = (dv[0], dv[1], dv[4]) if dv is not None else None
+        self._prepared = prep
+        dkw = dict(dec_ids=dec[0], dec_mask=dec[1], target_ids=dec[2]) if dec is not None else {}
         try:
-            out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True, fuse_optimizer=True)
+            out = self.forward_backward(input_ids, attention_mask, training=self.model.training, compute_grads=True, fuse_optimizer=True,
+                                        **dkw)
         finally:
             self._prepared = None
         self.optimizer_step()
         return out
 
-    def train_step(self, input_ids, attention_mask, prepared=None):
-        """One optimiser step.  Once a batch shape has been seen twice the step is replayed from a chain of hipGraphs
+    def train_step(self, input_ids, attention_mask, prepared=None, dec_ids=None, dec_mask=None, target_ids=None):
+        """One optimiser step.  dec_ids / dec_mask / target_ids: the decoder's own input and the loss target of a Bagon step
+        (models/bagon/Trainer.py:78-110; default: the autoencoding step, decoder input = target = input_ids).  prepared: see
+        _normalise_prepared().  Once a batch shape has been seen twice the step is replayed from a chain of hipGraphs
         (_StepGraphs: the quantiser and, on multi-GPU runs, the RCCL all-reduces stay eager launches between the graphs); the
         host then issues a handful of launches per step instead of ~800.  KVQ_GRAPH=0 keeps every launch eager."""
+        if dec_ids is None and (dec_mask is not None or target_ids is not None):
+            if target_ids is None:
+                raise KvqError("TrainEngine.train_step: dec_mask without dec_ids")
+            dec_ids, dec_mask = input_ids, attention_mask           # a separate target alone: the decoder still reads the encoder's ids
+        dec = (dec_ids, dec_mask, target_ids) if dec_ids is not None else None
+        key = (tuple(input_ids.shape), bool(self.model.training), tuple(dec_ids.shape) if dec is not None else None)
+        seen = self._eager_seen.get(key, 0)
+        prep = self._normalise_prepared(prepared, input_ids, dec_ids, check_ids=seen < 2)
         if not self.use_graph:
-            return self._train_step_eager(input_ids, attention_mask, prepared)
-        key = (tuple(input_ids.shape), bool(self.model.training))
+            self._eager_seen[key] = seen + 1
+            return self._train_step_eager(input_ids, attention_mask, prep, dec)
         g = self._graphs.get(key)
         if g is None:
-            seen = self._eager_seen.get(key, 0)
             if seen < 2 or len(self._graphs) >= 4:      # warm the workspaces / GEMM plans eagerly first; few shapes only
                 self._eager_seen[key] = seen + 1
-                return self._train_step_eager(input_ids, attention_mask, prepared)
+                return self._train_step_eager(input_ids, attention_mask, prep, dec)
             try:
-                g = self._graphs[key] = _StepGraphs(self, input_ids, attention_mask)
+                if prep["pack"] is not None:
+                    ids0, mask0, dv = prep["views"]
+                    dec0 = (dv[0], dv[1], dv[4]) if dv is not None else None
+                else:
+                    ids0, mask0, dec0 = input_ids, attention_mask, dec
+                g = self._graphs[key] = _StepGraphs(self, ids0, mask0, dec0)
             except Exception as e:                       # capture is an optimisation: never let it take a run down
                 import sys
                 print(f"[kvq] hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
                       f"continuing with eager launches", file=sys.stderr, flush=True)
                 self._abandon_capture()
-                return self._train_step_eager(input_ids, attention_mask, prepared)
-        return g.run(input_ids, attention_mask, prepared)
+                return self._train_step_eager(input_ids, attention_mask, prep, dec)
+        return g.run(input_ids, attention_mask, prep, dec)
 
     def _abandon_capture(self):
         """Leave a failed capture behind in a state from which eager steps can go on (same collectives, same order)."""
@@ -1676,5 +1776,6 @@ class TrainEngine:
         self._wg_items, self._wg_keep, self._wg_keep_step = [], [], []
         self._fuse_opt, self._adam_forked, self._adam_hi = False, False, self.flat.n
 
-    def eval_step(self, input_ids, attention_mask):
-        return self.forward_backward(input_ids, attention_mask, training=False, compute_grads=False)
+    def eval_step(self, input_ids, attention_mask, dec_ids=None, dec_mask=None, target_ids=None):
+        return self.forward_backward(input_ids, attention_mask, training=False, compute_grads=False, dec_ids=dec_ids, dec_mask=dec_mask,
+                                     target_ids=target_ids)

@@ -401,3 +401,35 @@ def gemm_fp8_nt(a8, b8, scale_a, scale_b, bias=None, out=None):
     check(lib().kvq_gemm_fp8_nt(a8.data_ptr(), b8.data_ptr(), scale_a.data_ptr(), scale_b.data_ptr(), _p(bias), out.data_ptr(), M, N, K,
                                 a8.stride(0), b8.stride(0), out.stride(0), stream_ptr()), "kvq_gemm_fp8_nt")
     return out
+
+
+# ---- clock probe (bench.py) -----------------------------------------------------------------------------------------------------
+def clock_probe():
+    """Launch kvq_clock_probe on the current stream; returns its [rows, 4] int64 result buffer (read it after a synchronisation)."""
+    l = lib()
+    out = torch.zeros((l.kvq_clock_probe_rows(), 4), dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+    check(l.kvq_clock_probe(out.data_ptr(), out.numel() * 8, stream_ptr()), "kvq_clock_probe")
+    return out
+
+
+def clock_mhz(p0, p1):
+    """Shader clock held between two clock_probe() results of one stream: per XCD (the cycle counter is the XCD's own) the first
+    stamp of each probe, d(s_memtime) / d(s_memrealtime) x 100 MHz; returns (median over the XCDs seen by both, {xcd: MHz})."""
+    a, b = p0.cpu().tolist(), p1.cpu().tolist()
+
+    def first(rows):
+        d = {}
+        for xcc, t, r, _ in rows:
+            if xcc not in d or r < d[xcc][1]:
+                d[xcc] = (t, r)
+        return d
+    fa, fb = first(a), first(b)
+    per = {}
+    for x in sorted(set(fa) & set(fb)):
+        dt, dr = fb[x][0] - fa[x][0], fb[x][1] - fa[x][1]
+        if dr > 0 and dt > 0:
+            per[int(x)] = dt / dr * 100.0
+    if not per:
+        return None, {}
+    v = sorted(per.values())
+    return v[len(v) // 2], per

@@ -15,6 +15,7 @@ VAL_SPLIT_PCT = 0.2
 BATCH_SIZE = 256
 NUM_WORKERS = 0
 PIN_MEMORY = True
+TOKEN_CACHE = True              # tokenise every split once, keep it in HBM, batches = device index_select (dsentences/token_cache.py)
 
 ENCODER_MODEL_NAME = "bert-base-uncased"
 DECODER_MODEL_NAME = "bert-base-uncased"
@@ -46,6 +47,7 @@ LIM_BATCHES_TRAIN_PCT = 1.0
 LIM_BATCHES_VAL_PCT = 1.0
 LIM_BATCHES_TEST_PCT = 1.0
 GRAD_BUCKET_MIB = 64
+USE_ENGINE = True               # kvq.engine.TrainEngine (explicit fwd/bwd on flat buffers, own HIP kernels) when the model shape allows
 
 RUNS_DIR = "./runs/Bagon"
 EXPORT_CHECKPOINT = True

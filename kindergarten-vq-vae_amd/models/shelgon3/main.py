@@ -112,6 +112,9 @@ def main():
                              milestones=MILESTONES if LR_SCHEDULER == "MultiStepLR" else None, gamma=GAMMA,
                              loss_recon_scale=LOSS_RECON_RESCALE_FACTOR * LOSS_RECON_WEIGHT,
                              loss_vq_scale=LOSS_VQ_RESCALE_FACTOR * LOSS_VQ_WEIGHT, bucket_mib=GRAD_BUCKET_MIB)
+        if TOKEN_CACHE:
+            for c in caches:          # the packed sort files the MODEL's padding row under -1 (not the tokenizer's pad id)
+                c.packed_pad_id = engine.pad_idx
     elif world > 1:
         grad_sync = ddp.GradSync(model.parameters(), bucket_mib=GRAD_BUCKET_MIB)
 

@@ -6,11 +6,14 @@ Follows, expression for expression:
     models/shelgon3/Trainer.py:82-115  pad to max_length, kl_div(log_softmax, one_hot) "batchmean", argmax(softmax),
                                        seq_acc, weighted sum, zero_grad / backward / Adam step / scheduler tick
     models/shelgon3/main.py:91         Adam over ALL model.parameters()
+    models/bagon/Bagon.py:40-55 + models/bagon/Trainer.py:96-130   the plain Bagon step (OracleBagon / bagon_step)
 The BERT blocks are HuggingFace's own classes (third-party part of the reference, transformers 5.15 in this image)
 built from a local BertConfig: encoder = BertModel, decoder = BertLMHeadModel(is_decoder, add_cross_attention)
 (what EncoderDecoderModel.from_encoder_decoder_pretrained builds, Bagon.py:24-31).
-Parity status: the VQ part is pinned by tests/golden; the composition has no reference-side fixture (the reference's
-Shelgon/Trainer do not import as checked in) -> "parity unpinned" for the composed step, stated in DESIGN.md.
+Parity status: the VQ part is pinned by tests/golden/vq_*.npz (the reference's own module); the compositions are pinned by
+tests/golden/step_tiny.npz and step_bagon_tiny.npz, which tests/golden/make_step*_golden.py produce from the pieces of the
+reference that run here (its VectorQuantizer and seq_acc, imported; HuggingFace's BERT classes) wired as the reference wires
+them -- the reference's Shelgon / Bagon / Trainer classes themselves do not import as checked in.
 """
 from __future__ import annotations
 
@@ -52,6 +55,40 @@ class OracleShelgon(nn.Module):
         vq_loss, z_q, perplexity, _enc, idx = self.vector_quantizer(embeds)                          # Shelgon.py:58
         logits = self.decoder(encoder_hidden_states=z_q, input_ids=input_ids, attention_mask=attention_mask).logits  # :71
         return vq_loss, perplexity, idx, logits
+
+
+class OracleBagon(nn.Module):
+    """models/bagon/Bagon.py:24-31 (what from_encoder_decoder_pretrained builds, from a local config) + :40-55 forward."""
+
+    def __init__(self, bert_cfg: dict):
+        super().__init__()
+        from transformers import BertConfig, BertLMHeadModel, BertModel
+        self.encoder = BertModel(BertConfig(**bert_cfg))
+        self.decoder = BertLMHeadModel(BertConfig(**bert_cfg, is_decoder=True, add_cross_attention=True))
+
+    def forward(self, encoder_input_ids, encoder_attention_mask, decoder_input_ids, decoder_attention_mask):
+        encoder_output = self.encoder(encoder_input_ids, attention_mask=encoder_attention_mask).last_hidden_state      # Bagon.py:46-48
+        return self.decoder(encoder_hidden_states=encoder_output, input_ids=decoder_input_ids,
+                            attention_mask=decoder_attention_mask).logits                                             # Bagon.py:50-53
+
+
+def bagon_step(model, opt, ids_enc, mask_enc, ids_dec, mask_dec, vocab_size, lr_sched=None):
+    """models/bagon/Trainer.py:96-130 (tokenisation and perturbation happen upstream: both id sets are given).  The target of
+    the loss and of the accuracies is the decoder's input as given (i.e. after its perturbation, Trainer.py:94,103)."""
+    logits = model(ids_enc, mask_enc, ids_dec, mask_dec)
+    loss_recon = kl_div(input=log_softmax(logits.reshape(-1, vocab_size), dim=-1),
+                        target=one_hot(ids_dec, vocab_size).reshape(-1, vocab_size).float(), reduction="batchmean")
+    recon_ids = torch.argmax(softmax(logits, dim=-1), dim=-1)
+    hits = (recon_ids - ids_dec) == 0                                                                  # common/metrics.py:18-22
+    acc_batch, acc_sentence = hits.sum() / recon_ids.numel(), torch.mean(hits.float(), dim=-1)         # common/metrics.py:30-34
+    if opt is not None:
+        opt.zero_grad()
+        loss_recon.backward()
+        opt.step()
+        if lr_sched is not None:
+            lr_sched.step()
+    return dict(loss_recon=loss_recon.detach(), loss_full=loss_recon.detach(), acc_batch=acc_batch, acc_sentence=acc_sentence,
+                recon_ids=recon_ids, logits=logits.detach())
 
 
 def step(model, opt, input_ids, attention_mask, vocab_size, w_recon=1.0, w_vq=1.0, lr_sched=None):

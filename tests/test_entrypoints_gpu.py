@@ -73,18 +73,33 @@ def test_shelgon_main_with_sentences_padded_to_40_tokens(tmp_path):
     assert os.path.exists(run + "/shelgon_ckpt_loss_recon_val_best.pth")
 
 
-def test_bagon_main_end_to_end(tmp_path):
+@pytest.mark.parametrize("use_engine,perturb", [(True, 0.0), (False, 0.0), (True, 0.1)])
+def test_bagon_main_end_to_end(tmp_path, use_engine, perturb):
+    """models/bagon/main.py on the TrainEngine (token cache, packed batches), on the autograd path (DataLoader + per-step
+    tokenizer), and on the engine with token noise on BOTH sides (encoder ids != decoder ids in every step, Trainer.py:85,94)."""
     run = _run("models/bagon/main.py", tmp_path, lambda d: {
         "KVQ_DATASET_PATH": repr(d + "/dSentences_sentences_clean.npy"),
         "KVQ_LATENT_CLASSES_LABELS_PATH": repr(d + "/dSentences_latent_classes_labels_clean.npy"),
         "KVQ_LATENT_CLASSES_ONE_HOT_PATH": repr(d + "/dSentences_latent_classes_one_hot_clean.npy"),
-        "KVQ_MODEL_MODE": "'dec-head-ft'"})
+        "KVQ_MODEL_MODE": "'dec-head-ft'", "KVQ_USE_ENGINE": str(use_engine), "KVQ_TOKEN_CACHE": str(use_engine),
+        "KVQ_ENCODER_PERTURB_TRAIN_PCT": str(perturb), "KVQ_DECODER_PERTURB_TRAIN_PCT": str(perturb),
+        "KVQ_DECODER_PERTURB_VAL_PCT": str(perturb)})
     ckpt = torch.load(run + "/bagon_ckpt_loss_recon_val_best.pth", map_location="cpu")
     assert set(ckpt) == {"model_state_dict", "encoder_state_dict", "decoder_state_dict"}
     conf = json.load(open(run + "/run_conf.json"))
     assert conf["model_mode"] == "dec-head-ft" and conf["n_params"]["encoder"]["n_trainable_params"] == 0
+    assert conf["use_engine"] == use_engine and conf["decoder_perturb_train_pct"] == perturb
     logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
     assert any("test/loss_recon" in l for l in logs)
+    assert {"train/loss_recon", "train/loss_full", "train/acc", "padding_tokens_pct/train"} <= {k for l in logs for k in l}     # Trainer.py:196-203
+    tr = [l["train/loss_recon"] for l in logs if "train/loss_recon" in l]
+    assert len(tr) == 2 and tr[1] < tr[0]                                                     # it learns
+    import pandas as pd
+    df = pd.read_feather(run + "/decoded_sentences.feather")
+    assert {"epoch", "stage", "input_sentence", "recon_sentence", "sentence_acc", "sentence_type", "verb_tense"} <= set(df.columns)
+    assert len(df) > 0 and df["sentence_acc"].between(0, 1).all()
+    if perturb:
+        return
     # common/test_checkpoint_validity.py of the reference: load that checkpoint into a fresh Bagon and reconstruct the probe sentences
     env = dict(os.environ, PYTHONPATH=PKG, KVQ_CKPT_PATH=repr(run + "/bagon_ckpt_loss_recon_val_best.pth"),
                KVQ_ENCODER_MODEL_NAME="'kvq-bert-tiny'", KVQ_DECODER_MODEL_NAME="'kvq-bert-tiny'")
