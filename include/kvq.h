@@ -294,6 +294,8 @@ int kvq_attn_set_variant(int variant);
 #define KVQ_GEMM_TILE_128x256 1   /* 8 waves */
 #define KVQ_GEMM_TILE_256x192 2   /* 8 waves */
 #define KVQ_GEMM_TILE_256x256 3   /* 8 waves */
+#define KVQ_GEMM_TILE_64x128 4    /* 4 waves, two workgroups per CU: outputs too small to give every CU a larger tile (the reference's own
+                                   * batches: 12 tokens x 64..128 sentences, models/shelgon3/Trainer.py:82) */
 /* OR-ed into `tile` (layout NT, one problem, no accumulate, M and N at least one tile, K >= 192): the PERSISTENT form -- one
  * workgroup per CU walks its tiles, the k-tiles of successive tiles form one uninterrupted LDS-DMA stream and the epilogue
  * goes from the accumulator registers straight to memory; pays when a CU owns two or more tiles. */
@@ -309,6 +311,12 @@ typedef struct kvq_gemm_problem {
 } kvq_gemm_problem;
 int kvq_gemm_bf16(const void* A, const void* B, const void* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                   int layout, int tile, int accumulate, void* stream);
+/* The any-shape member of the family (csrc/kvq_gemm_any.hip): same layouts and meaning, NO divisibility or 16-byte alignment
+ * requirement (any M, N, K, leading dimensions; 2-byte aligned operands); f32 accumulation in ascending k on the vector unit.
+ * For the launch-latency-sized products that do not meet kvq_gemm_bf16's requirements (token counts that are not multiples of
+ * 64, 9-code Gumbel logits, ...), so that no product of the bf16 step leaves the library. */
+int kvq_gemm_any_bf16(const void* A, const void* B, const void* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      int layout, int accumulate, void* stream);
 int kvq_gemm_grouped_bf16(const kvq_gemm_problem* problems, int n_problems, int layout, int tile, void* stream);
 /* BertIntermediate in one kernel (modeling_bert.py:325-337), layout NT: Hout = A.B^T + bias (kept for backward) and
  * Aout = gelu(Hout as rounded to bf16) -- exact-erf GELU (erf to 1.2e-7).  tile: KVQ_GEMM_TILE_256x192 or _128x256, optionally
@@ -354,7 +362,8 @@ int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const 
 
 /* torch.optim.Adam step (models/shelgon3/main.py:91: lr, weight_decay (L2, coupled), amsgrad) on flat buffers.
  *   p, m, v [, vmax] f32; g grad_dtype (scaled by grad_scale first); shadow_bf16 (may be NULL) receives bf16(p_new).
- *   step >= 1 is the 1-based step count for bias correction.  n %% 4 == 0. */
+ *   step >= 1 is the 1-based step count for bias correction.  Any n >= 1 (16-byte aligned buffers; the last n %% 4 elements take a
+ *   scalar path: the 9-code Gumbel bias of the reference's analysis run). */
 int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                   void* stream);

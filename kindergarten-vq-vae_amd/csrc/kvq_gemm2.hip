@@ -1100,6 +1100,7 @@ template <bool AK, bool BKM> using Cfg256x192 = Cfg<256, 192, 4, 2, AK, BKM, 2>;
 template <bool AK, bool BKM> using Cfg128x192 = Cfg<128, 192, 2, 4, AK, BKM, 3>;     // 8 waves, 120 KiB: 256 tiles at N = 768
 template <bool AK, bool BKM> using Cfg256x256 = Cfg<256, 256, 2, 4, AK, BKM, 2>;     // 8 waves, 128 KiB
 template <bool AK, bool BKM> using Cfg128x192p = Cfg<128, 192, 4, 2, AK, BKM, 3>;    // persistent form: an even number of 16-column blocks per wave
+template <bool AK, bool BKM> using Cfg64x128 = Cfg<64, 128, 1, 4, AK, BKM, 3>;       // 4 waves, 72 KiB: two workgroups per CU, small outputs
 
 template <class C, int EPI = EPI_NONE>
 static int launch_cfg(const Params& P, hipStream_t st) {
@@ -1165,6 +1166,7 @@ static void tile_of(int tile, int& bm, int& bn) {
         case KVQ_GEMM_TILE_128x256: bm = 128; bn = 256; break;
         case KVQ_GEMM_TILE_256x192: bm = 256; bn = 192; break;
         case KVQ_GEMM_TILE_256x256: bm = 256; bn = 256; break;
+        case KVQ_GEMM_TILE_64x128: bm = 64; bn = 128; break;
         default: bm = 128; bn = 192; break;
     }
 }
@@ -1179,7 +1181,8 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
     KVQ_REQUIRE(layout == KVQ_GEMM_NT || layout == KVQ_GEMM_NN || layout == KVQ_GEMM_TN, "%s: unknown layout %d", who, layout);
     const bool persistent = (tile & KVQ_GEMM_PERSISTENT) != 0;
     tile &= ~KVQ_GEMM_PERSISTENT;
-    KVQ_REQUIRE(tile >= KVQ_GEMM_TILE_128x192 && tile <= KVQ_GEMM_TILE_256x256, "%s: unknown tile %d", who, tile);
+    KVQ_REQUIRE(tile >= KVQ_GEMM_TILE_128x192 && tile <= KVQ_GEMM_TILE_64x128, "%s: unknown tile %d", who, tile);
+    KVQ_REQUIRE(!(persistent && tile == KVQ_GEMM_TILE_64x128), "%s: the 64x128 tile has no persistent form", who);
     int bm, bn;
     g2::tile_of(tile, bm, bn);
     (void)persistent;
@@ -1251,6 +1254,7 @@ int kvq_gemm_grouped_bf16(const kvq_gemm_problem* probs, int nprob, int layout, 
         case KVQ_GEMM_TILE_128x256: return g2::launch_layout<g2::Cfg128x256>(layout, P, st);
         case KVQ_GEMM_TILE_256x192: return g2::launch_layout<g2::Cfg256x192>(layout, P, st);
         case KVQ_GEMM_TILE_256x256: return g2::launch_layout<g2::Cfg256x256>(layout, P, st);
+        case KVQ_GEMM_TILE_64x128: return g2::launch_layout<g2::Cfg64x128>(layout, P, st);
         default: return g2::launch_layout<g2::Cfg128x192>(layout, P, st);
     }
 }

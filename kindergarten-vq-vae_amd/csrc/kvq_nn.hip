@@ -831,7 +831,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                     float* __restrict__ v, float* __restrict__ vmax,
                                                     unsigned short* __restrict__ shadow, int64_t n4, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    float grad_scale, const float* __restrict__ hyper) {
+                                                    float grad_scale, const float* __restrict__ hyper, int n_tail) {
     if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }     // device-resident step state (kvq_step_state_advance)
     const int64_t n8 = n4 >> 1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
@@ -853,6 +853,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         adam_update4(pv, IO<DT_G>::load4(g, e) * grad_scale, mv, vv, vmax ? vmax + e : nullptr, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
         *reinterpret_cast<f32x4*>(p + e) = pv; *reinterpret_cast<f32x4*>(m + e) = mv; *reinterpret_cast<f32x4*>(v + e) = vv;
         if (shadow) IO<KVQ_BF16>::store4(shadow, e, pv);
+    }
+    if (n_tail && blockIdx.x == 0 && threadIdx.x == 1) {                    // 1 .. 3 last elements (9-code Gumbel bias, ...)
+        for (int64_t e = 4 * n4; e < 4 * n4 + n_tail; ++e) {
+            f32x4 pv = {p[e], 0.f, 0.f, 0.f}, mv = {m[e], 0.f, 0.f, 0.f}, vv = {v[e], 0.f, 0.f, 0.f};
+            float vm4[4] = {vmax ? vmax[e] : 0.f, 0.f, 0.f, 0.f};
+            const f32x4 gv = {IO<DT_G>::load1(g, e) * grad_scale, 0.f, 0.f, 0.f};
+            adam_update4(pv, gv, mv, vv, vmax ? vm4 : nullptr, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+            p[e] = pv.x; m[e] = mv.x; v[e] = vv.x;
+            if (vmax) vmax[e] = vm4[0];
+            if (shadow) IO<KVQ_BF16>::store1(shadow, e, pv.x);
+        }
     }
 }
 
@@ -2577,16 +2588,20 @@ int kvq_gelu_bwd(const void* h, const void* g_a, void* g_h, int64_t n, int io_dt
 static int adam_launch(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
                        float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2s, float grad_scale,
                        const float* hyper, void* stream) {
-    KVQ_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0, "kvq_adam_step: bad argument (n %% 4 == 0)");
+    KVQ_REQUIRE(p && g && m && v && n > 0, "kvq_adam_step: bad argument");
+    KVQ_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax | (uintptr_t)shadow_bf16) & 15) == 0,
+                "kvq_adam_step: 16-byte aligned buffers required");
     const int64_t n4 = n / 4;
+    const int n_tail = (int)(n - 4 * n4);
     const int64_t n8 = (n4 + 1) / 2;
     unsigned blocks = (unsigned)((n8 + 255) / 256 > 32768 ? 32768 : (n8 + 255) / 256);
+    if (blocks == 0) blocks = 1;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DT(grad_dtype,
                 hipLaunchKernelGGL(adam_kernel<KVQ_F32>, dim3(blocks), dim3(256), 0, st, p, g, m, v, vmax, (unsigned short*)shadow_bf16, n4,
-                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper),
+                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper, n_tail),
                 hipLaunchKernelGGL(adam_kernel<KVQ_BF16>, dim3(blocks), dim3(256), 0, st, p, g, m, v, vmax, (unsigned short*)shadow_bf16, n4,
-                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper));
+                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper, n_tail));
     return check_launch("adam_kernel");
 }
 

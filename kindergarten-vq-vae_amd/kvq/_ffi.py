@@ -33,7 +33,7 @@ class GemmProblem(C.Structure):
 
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-GEMM_TILE_128x192, GEMM_TILE_128x256, GEMM_TILE_256x192, GEMM_TILE_256x256 = 0, 1, 2, 3
+GEMM_TILE_128x192, GEMM_TILE_128x256, GEMM_TILE_256x192, GEMM_TILE_256x256, GEMM_TILE_64x128 = 0, 1, 2, 3, 4
 
 # name -> (restype, argtypes); mirrors include/kvq.h line by line
 SIGNATURES = {
@@ -89,6 +89,7 @@ SIGNATURES = {
     "kvq_attn_bwd_saved": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32,
                                   C.c_uint64, C.c_uint32, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
     "kvq_gemm_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "kvq_gemm_any_bf16": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_grouped_bf16": (_int, [C.POINTER(GemmProblem), _int, _int, _int, _vp]),
     "kvq_fp8_quantize": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp, _vp]),
     "kvq_fp8_state_floats": (_int, []),

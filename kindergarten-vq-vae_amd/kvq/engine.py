@@ -14,8 +14,11 @@ This engine runs the same mathematics as an explicit forward / backward schedule
   multi-GPU gradients are laid out in forward order, so backward finishes them from the end of the buffer towards
             the start: fixed-size tail chunks are all-reduced (RCCL, AVG, bf16) on a side stream while backward continues
 
-GEMMs: csrc/kvq_gemm2.hip for every shape of the bf16 step at >= 2048 tokens (the selection tables _OWN_*); f32 runs, small
-batches and the Gumbel quantiser's two products go through torch.mm / addmm (hipBLASLt).  Everything else is libkvq.so.
+GEMMs: every product of the bf16 step runs in libkvq.so -- csrc/kvq_gemm2.hip (LDS-DMA + MFMA; the tile is chosen by the cost
+model kvq.nnops.pick_tile over (M, N, K), the persistent form by nnops.persistent_pays) or, for shapes that miss its divisibility /
+alignment requirements, csrc/kvq_gemm_any.hip.  No vendor-library GEMM is reachable from a bf16 engine
+(tests/test_engine_small_batches_gpu.py patches torch.mm / addmm / bmm / matmul to raise); the f32 engine, which exists as the
+checker of the bf16 one, multiplies with torch (hipBLASLt, tuning/tunableop_gfx950.csv).
 Math restated from HuggingFace modeling_bert.py (see kvq/bert.py for the line map); tests/test_engine_gpu.py checks
 losses and every parameter gradient against the autograd path (kvq.bert + torch autograd).
 """
@@ -363,11 +366,10 @@ class TrainEngine:
         self._graphs, self._eager_seen, self._cap, self._prepared = {}, {}, None, None
         self._own_fwd = os.environ.get("KVQ_OWN_GEMM", "1") != "0"
         self._gumbel_own = 0                  # products of the Gumbel mode that ran on the own GEMM (tests read it)
-        for attr, var in (("_OWN_FWD", "KVQ_OWN_FWD"), ("_OWN_DGRAD", "KVQ_OWN_DGRAD"), ("_OWN_GELU", "KVQ_OWN_GELU"),
-                          ("_OWN_DGELU", "KVQ_OWN_DGELU"), ("_OWN_WGRAD_SINGLE", "KVQ_OWN_WGRAD_SINGLE")):
-            if var in os.environ:       # "NxK:tile;NxK:tile" replaces the table (A/B runs on the GPU box); "" = all library
-                setattr(self, attr, {tuple(int(v) for v in e.split(":")[0].split("x")): e.split(":")[1]
-                                     for e in os.environ[var].split(";") if e})
+        if os.environ.get("KVQ_GEMM_TILE"):       # "NxK:tile;NxK:tile" (A/B runs on the GPU box)
+            self._TILE_OVERRIDE = {tuple(int(v) for v in e.split(":")[0].split("x")): e.split(":")[1]
+                                   for e in os.environ["KVQ_GEMM_TILE"].split(";") if e}
+        self._own_epi = os.environ.get("KVQ_OWN_EPI", "1") != "0"     # A/B switch: 0 = activations as separate kernels behind the GEMMs
         # weight gradients of a whole layer as ONE grouped launch of csrc/kvq_gemm2.hip (KVQ_OWN_WGRAD=0: library + split-K slabs)
         self._own_wgrad = self._own_fwd and os.environ.get("KVQ_OWN_WGRAD", "1") != "0" and self.dtype == torch.bfloat16
         self._wg_items, self._wg_keep = [], []
@@ -560,26 +562,10 @@ class TrainEngine:
         self._site_ctr += 1
         return self._site_ctr
 
-    # (N, K) -> workgroup tile of csrc/kvq_gemm2.hip for the shapes where it beats the tuned library at 8192 rows
-    # (tools/gemm2_probe.py on MI355X, interleaved rounds; gpurun_out/g2_probe*.log); every other shape stays with hipBLASLt
-    # "p" = the persistent tile loop (KVQ_GEMM_PERSISTENT), for shapes where a CU owns two or more tiles.  When it was built it won
-    # 10-12 % on QKV / FFN1 (tools/gemm2_probe_persist.py); the start-up fix of the one-tile kernel took most of
-    # that back: whole-step A/B on one box at the end of round 3 (tools/ab_env.sh) 17.28 ms with every "p" below, 17.31 with the QKV
-    # projection on the one-tile kernel, 17.23 with FFN1 + GELU on the one-tile kernel (hence no "p" there), cross-K/V a tie.
-    # The LM head keeps the one-tile kernel (327 us with column bands; persistent 346; library 332): with it the step has no
-    # vendor-library GEMM left.
-    _OWN_FWD = {(768, 768): "128x192", (768, 3072): "128x192", (2304, 768): "128x192p", (18432, 768): "256x256p",
-                (30528, 768): "256x256"}                                                    # y = x . W^T + b        ("nt")
-    _OWN_DGRAD = {(768, 768): "128x192", (768, 2304): "128x192", (768, 3072): "128x192", (3072, 768): "256x192",
-                  (768, 18432): "128x192", (768, 30528): "128x192"}                         # gx = gy . W            ("nn")
-    # BertIntermediate / its backward with the activation inside the GEMM epilogue: (N, K) -> tile.  One v_exp_f32 + one v_rcp_f32
-    # per element (Phi and phi share the exponential) and packed f32 FMAs; measured on MI355X (tools/gemm2_probe.py epi):
-    # FFN1 forward 57.7 us against 44.5 + 19.3 (GEMM + gelu kernel), FFN2 backward 65.6 against 45.3 + 29.8; in the step
-    # 19.07 -> 18.58 ms (gpurun_out/ab5.log).  KVQ_OWN_GELU="" / KVQ_OWN_DGELU="" switch back to the separate kernels.
-    _OWN_GELU = {(3072, 768): "256x192"}                                        # (h, gelu(h)) = x . W^T + b
-    _OWN_DGELU = {(3072, 768): "256x192"}                                       # (gy . W) * gelu'(h) + bias-gradient partials
-    _OWN_WGRAD_SINGLE = {(18432, 768): "256x256", (30528, 768): "128x256"}      # gW = gy^T . x          ("tn"), own launch
-    # (LM-head weight gradient: 128x256 329 us, 256x192 354, 256x256 373 in tools/gemm2_probe.py at round 3)
+    # Tile choice: kvq.nnops.pick_tile / persistent_pays (a cost model over (M, N, K) fitted to tools/gemm2_probe_small.py and
+    # consistent with the per-shape choices measured at 8192 rows in rounds 2 - 3, which it replaced).  KVQ_GEMM_TILE="NxK:tile;..."
+    # overrides it per weight shape for A/B runs on the GPU box.
+    _TILE_OVERRIDE: Dict[Tuple[int, int], str] = {}
 
     # ---- fp8 forward GEMMs -------------------------------------------------------------------------------------------------
     def _fp8_setup(self):
@@ -656,26 +642,41 @@ class TrainEngine:
             key = fused[0][0] if fused else wname
         if self.fp8 and key in self._w8_index and x.shape[0] >= 256 and W.shape[1] % 128 == 0 and x.stride(1) == 1:
             return self._linear_fp8(x, W, b, key)
-        if self._own_fwd and self.dtype == torch.bfloat16 and x.shape[0] >= 2048 and x.stride(1) == 1:
-            tile = self._OWN_FWD.get(tuple(W.shape))
-            if tile is not None:
-                return nnops.gemm(x, W, "nt", bias=b, tile=tile)
-        return torch.addmm(b, x, W.t())
+        return self._gemm(x, W, "nt", bias=b)
+
+    def _gemm(self, a, b, layout, bias=None, out=None, accumulate=False):
+        """op(a) . op(b) (+ bias) (accumulated into out).  bf16: libkvq.so, always (nnops.gemm: MFMA kernel or the any-shape one).
+        f32 (the checker engine) and KVQ_OWN_GEMM=0 (A/B against the vendor library): torch."""
+        if self._own_fwd and self.dtype == torch.bfloat16:
+            M, N, K = nnops._gemm_dims(a, b, layout)
+            wshape = (N, K) if layout == "nt" else ((K, N) if layout == "nn" else (M, N))
+            return nnops.gemm(a, b, layout, bias=bias, out=out, accumulate=accumulate, tile=self._TILE_OVERRIDE.get(wshape))
+        A = a.t() if layout == "tn" else a
+        Bm = b.t() if layout == "nt" else b
+        if out is not None and accumulate:
+            return out.addmm_(A, Bm)
+        if out is not None:
+            return torch.mm(A, Bm, out=out) if bias is None else torch.addmm(bias, A, Bm, out=out)
+        return torch.addmm(bias, A, Bm) if bias is not None else torch.mm(A, Bm)
+
+    def _epilogue_tile(self, M, N, K):
+        """Tile of the fused-activation GEMMs (they exist for 256 x 192 and 128 x 256), or None when the plain GEMM on its best
+        tile + the separate activation kernel (one pass over [M, N]: ~3 us + 4 bytes per element at ~3 TB/s) is modelled cheaper --
+        outputs too small to give half the CUs one of the large tiles."""
+        if not (self._own_fwd and self._own_epi and self.dtype == torch.bfloat16 and not self.fp8):
+            return None
+        t = nnops.pick_tile(M, N, K, candidates=("256x192", "128x256"))
+        plain = nnops.tile_cost_us(nnops.pick_tile(M, N, K), M, N, K) + 3.0 + M * N * 4 / 3e6
+        return nnops.TILE_NAMES[t] if nnops.tile_cost_us(t, M, N, K) <= plain else None
 
     def _linear_gelu(self, x, wname, bname):
         """(h, gelu(h)), h = x . W^T + b: one kernel where the own GEMM carries the activation in its epilogue."""
         W, b = self.flat.w(wname), self.flat.w(bname)
-        tile = self._OWN_GELU.get(tuple(W.shape)) if self._own_fwd and self.dtype == torch.bfloat16 and x.shape[0] >= 2048 \
-            and not self.fp8 else None               # (fp8 forward: the fp8 GEMM + the activation kernel)
-        if tile is not None and x.is_contiguous():
+        tile = self._epilogue_tile(x.shape[0], W.shape[0], W.shape[1])
+        if tile is not None and x.is_contiguous() and nnops.gemm_mfma_ok(x, W, None, "nt", b):
             return nnops.gemm_gelu(x, W, b, tile=tile)
         h = self._linear(x, wname, bname)
         return h, nnops.gelu_fwd(h)
-
-    # split-K factors for the weight-gradient GEMMs gW[M,N] = gy[Ntok,M]^T x[Ntok,N]: the contraction (Ntok = 8192) is long
-    # and the output small, so a single GEMM leaves most CUs idle; S batched slices + one sum fill the chip
-    # (measured with tools/gemm_probe.py on MI355X, hipBLASLt 1.0: 1.3-1.8x over the plain call)
-    _SPLITS = {(768, 768): 4, (2304, 768): 8, (3072, 768): 4, (768, 3072): 4, (1536, 768): 8}     # tools/wgrad_split_probe.py
 
     # ------------------------------------------------------------------------------------------------------------
     # deferred small reductions: a layer's split-K slab sums and LayerNorm / bias partial sums go out as ONE launch
@@ -764,23 +765,19 @@ class TrainEngine:
         return self._wgrad_on_current_stream(gy, x, out)
 
     def _wgrad_on_current_stream(self, gy, x, out):
+        """bf16: a launch of its own when the output alone fills half the CUs with 256 x 256 tiles (the LM head / all-layer
+        cross-K/V weight gradients), else queued for the layer's grouped launch; both contract over ALL tokens per tile (no split-K).
+        Token counts that are not multiples of 64 (the MFMA kernel's k-tile) go to the any-shape kernel."""
         Ntok, M = gy.shape
         N = x.shape[1]
-        if self._own_wgrad and Ntok % 64 == 0 and Ntok >= 2048 and gy.stride(1) == 1 and x.stride(1) == 1 and out.stride(1) == 1 \
-                and M % 8 == 0 and N % 8 == 0:
-            single = self._OWN_WGRAD_SINGLE.get((M, N))
-            if single is not None:
-                nnops.gemm(gy, x, "tn", out=out, tile=single)
+        if self._own_wgrad and nnops.gemm_mfma_ok(gy, x, out, "tn"):
+            if -(-M // 256) * -(-N // 256) >= 128:
+                self._gemm(gy, x, "tn", out=out)
             else:
                 self._wg_items.append(nnops.gemm_problem(gy, x, out, "tn"))
                 self._wg_keep += [gy, x]                       # alive until the grouped launch
             return
-        S = self._SPLITS.get((M, N), 0) if self.dtype == torch.bfloat16 else 0
-        if S and Ntok % S == 0 and Ntok // S >= 256 and gy.is_contiguous() and x.is_contiguous():
-            part = torch.bmm(gy.view(S, Ntok // S, M).transpose(1, 2), x.view(S, Ntok // S, N))
-            self._defer(part, out, S, M * N, M * N)
-        else:
-            torch.mm(gy.t(), x, out=out)
+        self._gemm(gy, x, "tn", out=out)
 
     def _linear_bwd(self, gy, x, wnames, bnames, need_gx=True, gx_accum=None, bias_done=False):
         """Weight / bias gradients straight into the flat gradient buffer; returns gx (or accumulates into gx_accum)."""
@@ -793,22 +790,13 @@ class TrainEngine:
             self._wgrad(gy, x, gW)
         if fl.trainable[bnames[0]] and not bias_done:     # bias_done: the LayerNorm backward kernel already produced it
             self._defer_colsum(gy, gb)
-        if self._own_fwd and self.dtype == torch.bfloat16 and gy.shape[0] >= 2048 and gy.stride(1) == 1 and (need_gx or gx_accum is not None):
-            tile = self._OWN_DGRAD.get((W.shape[1], W.shape[0]))
-            if tile is not None and (gx_accum is None or gx_accum.stride(1) == 1):
-                return nnops.gemm(gy, W, "nn", out=gx_accum, accumulate=gx_accum is not None, tile=tile)
         if gx_accum is not None:
-            gx_accum.addmm_(gy, W)
-            return gx_accum
-        return torch.mm(gy, W) if need_gx else None
+            return self._gemm(gy, W, "nn", out=gx_accum, accumulate=True)
+        return self._gemm(gy, W, "nn") if need_gx else None
 
     def _dgrad(self, gy, W):
         """gx = gy . W for a gradient that is not paired with a weight / bias gradient here (LM head, batched cross-K/V)."""
-        if self._own_fwd and self.dtype == torch.bfloat16 and gy.shape[0] >= 2048 and gy.stride(1) == 1 and W.stride(1) == 1:
-            tile = self._OWN_DGRAD.get((W.shape[1], W.shape[0]))
-            if tile is not None:
-                return nnops.gemm(gy, W, "nn", tile=tile)
-        return torch.mm(gy, W)
+        return self._gemm(gy, W, "nn")
 
     # ------------------------------------------------------------------------------------------------------------
     # blocks: forward returns (output, saved); backward consumes saved
@@ -978,8 +966,8 @@ class TrainEngine:
                                 g_beta=fl.g(pre + "ln2.b") if tr[pre + "ln2.b"] else None,
                                 g_bias_prev=fl.g(pre + "f2.b") if tr[pre + "f2.b"] else None)
         W2 = fl.w(pre + "f2.w")
-        tile = self._OWN_DGELU.get((W2.shape[1], W2.shape[0])) if self._own_fwd and self.dtype == torch.bfloat16 else None
-        if tile is not None and g_f.shape[0] >= 2048 and g_f.is_contiguous() and h.is_contiguous():
+        tile = self._epilogue_tile(g_f.shape[0], W2.shape[1], W2.shape[0])
+        if tile is not None and g_f.is_contiguous() and h.is_contiguous() and nnops.gemm_mfma_ok(g_f, W2, None, "nn"):
             # input gradient of f2, the activation's derivative and the f1-bias partial sums in ONE kernel
             self._linear_bwd(g_f, a, [pre + "f2.w"], [pre + "f2.b"], need_gx=False, bias_done=True)      # queues the f2 weight gradient
             g_h, pb = nnops.gemm_dgelu(g_f, W2, h, tile=tile)
@@ -1486,19 +1474,11 @@ class TrainEngine:
 
     # ---- GumbelQuantizer (models/shelgon3/GumbelQuantizer.py:43-83): 1x1 conv = GEMM, row kernel, codebook GEMM ----------------
     def _mm(self, a, b, layout, bias=None):
-        """op(a) . op(b) (+ bias) for the six products of the Gumbel mode.  bf16 at step sizes -> csrc/kvq_gemm2.hip (its tiles want
-        the contraction in multiples of 64 and M, N, leading dimensions in multiples of 8, which n_embed = 512 codes meets and the
-        reference analysis' 9 codes do not); anything else -> torch (hipBLASLt).  layout as nnops.gemm: "nt" | "nn" | "tn"."""
-        M, N, K = nnops._gemm_dims(a, b, layout)
-        own = self._own_fwd and self.dtype == torch.bfloat16 and a.dtype == b.dtype == torch.bfloat16 and a.shape[0] >= 2048 \
-            and K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and a.stride(1) == 1 and b.stride(1) == 1 \
-            and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
-        if own:
+        """op(a) . op(b) (+ bias) for the six products of the Gumbel mode (n_embed = 512 codes meets the MFMA kernel's requirements,
+        the reference analysis' 9 codes go to the any-shape kernel).  layout as nnops.gemm: "nt" | "nn" | "tn"."""
+        if self._own_fwd and self.dtype == torch.bfloat16:
             self._gumbel_own += 1
-            return nnops.gemm(a, b, layout, bias=bias)
-        A = a.t() if layout == "tn" else a
-        Bm = b.t() if layout == "nt" else b
-        return torch.addmm(bias, A, Bm) if bias is not None else A @ Bm
+        return self._gemm(a, b, layout, bias=bias)
 
     def _gumbel_forward(self, z, training):
         gq = self.model.vector_quantizer

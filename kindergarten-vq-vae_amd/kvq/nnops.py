@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch
 
-from ._ffi import check, io_dtype_of, lib, require_gpu, stream_ptr
+from ._ffi import KvqError, check, io_dtype_of, lib, require_gpu, stream_ptr
 from .functional import _workspace
 
 
@@ -274,11 +274,10 @@ def embed_grad(g, perm, sorted_ids, gW, accumulate=False):
 
 # ---- the GEMM family of csrc/kvq_gemm2.hip ---------------------------------------------------------------------------------
 _LAYOUTS = {"nt": 0, "nn": 1, "tn": 2}
-TILES = {"128x192": 0, "128x256": 1, "256x192": 2, "256x256": 3,
+TILES = {"128x192": 0, "128x256": 1, "256x192": 2, "256x256": 3, "64x128": 4,
          "128x192p": 0x100, "128x256p": 0x101, "256x192p": 0x102, "256x256p": 0x103}      # p: KVQ_GEMM_PERSISTENT (layout nt only)
-_TILE_DIMS = {0: (128, 192), 1: (128, 256), 2: (256, 192), 3: (256, 256)}
-
-
+TILE_NAMES = {v: k for k, v in TILES.items()}
+_TILE_DIMS = {0: (128, 192), 1: (128, 256), 2: (256, 192), 3: (256, 256), 4: (64, 128)}
 def _gemm_dims(a, b, layout):
     if layout == "nt":
         (M, K), N = a.shape, b.shape[0]
@@ -289,18 +288,57 @@ def _gemm_dims(a, b, layout):
     return M, N, K
 
 
-def pick_tile(M, N, n_cu=256):
-    """Workgroup tile for an [M, N] output: the candidate whose tile count wastes the least of the last round of 256 CUs,
-    larger tiles (more FLOP per staged byte) winning ties."""
-    best, best_key = 0, None
-    for t, (bm, bn) in _TILE_DIMS.items():
-        n = -(-M // bm) * -(-N // bn)
-        rounds = -(-n // n_cu)
-        eff = (M * N) / (rounds * n_cu * bm * bn)               # useful fraction of the MFMA slots of all rounds
-        key = (round(eff, 2), bm * bn)
-        if best_key is None or key > best_key:
-            best, best_key = t, key
-    return best
+# Cost model of one launch, microseconds, fitted to tools/gemm2_probe_small.py on MI355X (profiles/r04_gemm_small.md: 72 products at
+# 768 .. 6144 rows x 5 tiles; mean regret of the model's pick against the best measured tile 0.7 %, worst 17 %) and consistent with
+# the choices measured at 8192 rows in rounds 2 - 3 (tools/gemm2_probe.py):
+#   per 64-deep k-tile of ONE workgroup: _TK_ALONE when few CUs are busy (operands come from L2 unopposed), _TK_FULL when all 256
+#   are (the L2 -> LDS fill is shared); linear in the busy fraction between.  _T_TILE: start-up + epilogue of a tile.
+#   The 64 x 128 tile (4 waves, 72 KiB of LDS) runs two workgroups per CU, which together take _TK_PAIR per k-tile.
+_TK_ALONE = {0: 0.459, 1: 0.557, 2: 0.891, 3: 1.035, 4: 0.296}
+_TK_FULL = {0: 0.825, 1: 0.98, 2: 1.5, 3: 1.83, 4: 0.40}
+_TK_PAIR = (0.45, 0.52)
+_T_TILE = {0: 1.5, 1: 2.0, 2: 2.5, 3: 3.0, 4: 1.0}
+
+
+def tile_cost_us(t, M, N, K, n_cu=256):
+    """Modelled duration of an [M, N] x K product on tile t (see the table above)."""
+    bm, bn = _TILE_DIMS[t]
+    n = -(-M // bm) * -(-N // bn)
+    kt = max(K // 64, 1)
+    f = min(n, n_cu) / n_cu
+    lerp = lambda a, b: a + (b - a) * f
+    w = -(-n // n_cu)                                    # workgroups the busiest CU runs
+    if t == 4:
+        return kt * ((w // 2) * lerp(*_TK_PAIR) + (w % 2) * lerp(_TK_ALONE[t], _TK_FULL[t])) + w * _T_TILE[t]
+    return w * (kt * lerp(_TK_ALONE[t], _TK_FULL[t]) + _T_TILE[t])
+
+
+def pick_tile(M, N, K=768, n_cu=256, candidates=None):
+    """Workgroup tile for an [M, N] x K product: the cheapest under tile_cost_us() -- the rule over (M, N, K) that replaced the
+    engine's exact-shape tables (VERDICT r3 #3).  candidates: restrict the choice (the fused-activation epilogues exist for two tiles)."""
+    cand = list(_TILE_DIMS) if candidates is None else [TILES[c] if isinstance(c, str) else c for c in candidates]
+    return min(cand, key=lambda t: (tile_cost_us(t, M, N, K, n_cu), -_TILE_DIMS[t][0] * _TILE_DIMS[t][1]))
+
+
+def persistent_pays(t, M, N, K, layout, accumulate=False, n_cu=256):
+    """The persistent tile loop (KVQ_GEMM_PERSISTENT: NT only, whole tiles, no accumulate) instead of one tile per workgroup:
+    when a CU owns 3 .. 12 tiles.  Measured at 8192 rows (tools/gemm2_probe_persist.py, DESIGN.md section 2.3): QKV (3 tiles per CU)
+    and the all-layer cross-K/V projection (9) gain 1 - 4 %, two tiles per CU (FFN1) lose, the LM head (15, column bands) loses 6 %."""
+    bm, bn = _TILE_DIMS[t]
+    if layout != "nt" or accumulate or t == 4 or M < bm or N < bn or K // 64 < 3:
+        return False
+    per_cu = -(-(-(-M // bm) * -(-N // bn)) // n_cu)
+    return 3 <= per_cu <= 12
+
+
+def gemm_mfma_ok(a, b, out, layout, bias=None):
+    """True when kvq_gemm_bf16 (LDS-DMA + MFMA, csrc/kvq_gemm2.hip) takes this product: K % 64 == 0; M, N and the leading dimensions
+    in multiples of 8; 16-byte aligned operands (bias: 8); unit column stride."""
+    M, N, K = _gemm_dims(a, b, layout)
+    ts = [a, b] + ([out] if out is not None else [])
+    return K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and M >= 8 and N >= 8 \
+        and all(t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 for t in ts) \
+        and (bias is None or (bias.data_ptr() % 8 == 0 and bias.stride(0) == 1))
 
 
 def gemm_problem(a, b, out, layout, bias=None, accumulate=False):
@@ -313,13 +351,31 @@ def gemm_problem(a, b, out, layout, bias=None, accumulate=False):
 
 
 def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
-    """out[M,N] (= | +=) op(a) @ op(b) (+ bias), bf16 with f32 accumulation on the MFMA GEMM of csrc/kvq_gemm2.hip.
-    layout "nt": a[M,K], b[N,K];  "nn": a[M,K], b[K,N];  "tn": a[K,M], b[K,N]."""
+    """out[M,N] (= | +=) op(a) @ op(b) (+ bias), bf16 with f32 accumulation.  layout "nt": a[M,K], b[N,K];  "nn": a[M,K], b[K,N];
+    "tn": a[K,M], b[K,N].  The MFMA GEMM of csrc/kvq_gemm2.hip whenever the product meets its requirements (gemm_mfma_ok), tile
+    from pick_tile() unless given; the any-shape kernel of csrc/kvq_gemm_any.hip otherwise.  Never a vendor library."""
     require_gpu(a, b)
     M, N, K = _gemm_dims(a, b, layout)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or (out is not None and out.dtype != torch.bfloat16):
+        raise KvqError(f"kvq.nnops.gemm: bf16 operands only (got {a.dtype}, {b.dtype})")
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    t = pick_tile(M, N) if tile is None else (TILES[tile] if isinstance(tile, str) else tile)
+    if not gemm_mfma_ok(a, b, out, layout, bias):
+        if a.stride(1) != 1:
+            a = a.contiguous()
+        if b.stride(1) != 1:
+            b = b.contiguous()
+        if out.stride(1) != 1 or (bias is not None and bias.stride(0) != 1):
+            raise KvqError("kvq.nnops.gemm: output rows / bias must be contiguous")
+        check(lib().kvq_gemm_any_bf16(a.data_ptr(), b.data_ptr(), _p(bias), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                                      _LAYOUTS[layout], int(accumulate), stream_ptr()), "kvq_gemm_any_bf16")
+        return out
+    if tile is None:
+        t = pick_tile(M, N, K)
+        if persistent_pays(t, M, N, K, layout, accumulate):
+            t |= 0x100
+    else:
+        t = TILES[tile] if isinstance(tile, str) else tile
     check(lib().kvq_gemm_bf16(a.data_ptr(), b.data_ptr(), _p(bias), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                               _LAYOUTS[layout], t, int(accumulate), stream_ptr()), "kvq_gemm_bf16")
     return out

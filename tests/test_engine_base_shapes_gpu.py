@@ -168,7 +168,11 @@ def test_every_own_gemm_of_the_engine_step_against_f32_matmul_of_its_operands(mo
             want = want.to(torch.bfloat16).float() + before
         judge(o, want, f"gemm {layout} {tuple(o.shape)} K={a.shape[1] if layout != 'tn' else a.shape[0]} tile={tile} acc={accumulate}")
         seen[layout] += 1
-        seen["persistent"] += isinstance(tile, str) and tile.endswith("p")
+        if tile is None:                              # the engine leaves the choice to the rule (nnops.pick_tile / persistent_pays)
+            M_, N_, K_ = nnops._gemm_dims(a, b, layout)
+            seen["persistent"] += nnops.persistent_pays(nnops.pick_tile(M_, N_, K_), M_, N_, K_, layout, accumulate)
+        else:
+            seen["persistent"] += isinstance(tile, str) and tile.endswith("p")
         return o
 
     def gemm_gelu(x, w, bias, tile="256x192"):
@@ -207,8 +211,11 @@ def test_every_own_gemm_of_the_engine_step_against_f32_matmul_of_its_operands(mo
     assert np.isfinite(out["loss_recon"].item()) and not recorded
     print("own GEMM launches checked inside the engine step:", seen, "worst:", worst)
     # 2 + 2 layers: every family ran, the persistent forward kernel (the four QKV projections) included
-    assert seen["nt"] >= 12 and seen["nn"] >= 14 and seen["tn"] >= 1 and seen["gelu"] == 4 and seen["dgelu"] == 4
-    assert seen["grouped"] >= 20 and seen["persistent"] >= 4
+    # (gelu: the four FFN1 projections + the prediction head's transform, which the epilogue rule now takes as well)
+    assert seen["nt"] >= 12 and seen["nn"] >= 14 and seen["tn"] >= 1 and seen["gelu"] in (4, 5) and seen["dgelu"] == 4
+    # (persistent: at 2048 rows only the all-layer cross-K/V projection gives a CU three tiles or more; at the benchmarked 8192 rows
+    #  the QKV projections run persistent as well -- nnops.persistent_pays; the persistent kernel alone: tests/test_gemm2_gpu.py)
+    assert seen["grouped"] >= 20 and seen["persistent"] >= 1
 
 
 def test_engine_graph_step_at_bert_base_shapes_trains():

@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TILES = ["128x192", "128x256", "256x192", "256x256"]
+TILES = ["128x192", "128x256", "256x192", "256x256", "64x128"]
 
 
 def _ops(layout, M, N, K, seed=0, lda_pad=0):
@@ -113,12 +113,18 @@ def test_grouped_weight_gradients_of_two_decoder_layers():
 
 
 def test_gemm_rejects_bad_arguments():
+    """The MFMA entry point refuses what it cannot take (the C ABI's contract); nnops.gemm routes such a product to the any-shape
+    kernel instead, and refuses only what neither takes (f32 operands)."""
     from kvq import nnops
-    from kvq._ffi import KvqError
+    from kvq._ffi import KvqError, check, lib, stream_ptr
     a = torch.zeros((64, 100), device="cuda", dtype=torch.bfloat16)
     b = torch.zeros((64, 100), device="cuda", dtype=torch.bfloat16)
+    out = torch.empty((64, 64), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(KvqError):                      # K = 100 is not a multiple of 64
+        check(lib().kvq_gemm_bf16(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), 64, 64, 100, 100, 100, 64, 0, 0, 0, stream_ptr()), "kvq_gemm_bf16")
+    assert torch.equal(nnops.gemm(a, b, "nt"), torch.zeros_like(out))
     with pytest.raises(KvqError):
-        nnops.gemm(a, b, "nt")                      # K = 100 is not a multiple of 64
+        nnops.gemm(a.float(), b.float(), "nt")
 
 
 def _gelu(x):
@@ -263,3 +269,50 @@ def test_lm_head_gemm_with_loss_statistics(M, N, V, K):
     torch.testing.assert_close(out1[0], kl, rtol=2e-5, atol=1e-6)
     assert torch.equal(pred1, torch.softmax(lg, dim=-1).argmax(-1)) or (pred1 != lg.argmax(-1)).sum().item() == 0
     torch.testing.assert_close(out1[1], (pred1 == tgt).float().mean(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("shape", [(72, 128, 128), (72, 9, 128), (100, 2048, 72), (7, 5, 3), (333, 130, 129), (768, 768, 768)])
+def test_gemm_any_shape_kernel(layout, shape):
+    """csrc/kvq_gemm_any.hip: products the MFMA kernel refuses (K not a multiple of 64, odd M / N / leading dimensions, 2-byte
+    aligned views) -- what nnops.gemm routes there -- plus one it would take, called directly; bias and accumulate."""
+    from kvq import nnops
+    from kvq._ffi import check, lib, stream_ptr
+    M, N, K = shape
+    a, b, ref = _ops(layout, M, N, K, seed=M + N + K)
+    bias = torch.randn(N, device="cuda").to(torch.bfloat16)
+    out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    check(lib().kvq_gemm_any_bf16(a.data_ptr(), b.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), N,
+                                  {"nt": 0, "nn": 1, "tn": 2}[layout], 0, stream_ptr()), "kvq_gemm_any_bf16")
+    want = ref + bias.float()
+    assert (out.float() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item() + 1e-3
+    if not nnops.gemm_mfma_ok(a, b, out, layout, bias):
+        routed = nnops.gemm(a, b, layout, bias=bias)                       # the router sends it to the same kernel: same bits
+        assert torch.equal(routed, out)
+    before = out.float().clone()
+    check(lib().kvq_gemm_any_bf16(a.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, N, K, a.stride(0), b.stride(0), N,
+                                  {"nt": 0, "nn": 1, "tn": 2}[layout], 1, stream_ptr()), "kvq_gemm_any_bf16")
+    want2 = ref.to(torch.bfloat16).float() + before
+    assert (out.float() - want2).abs().max().item() <= 2.0 ** -7 * want2.abs().max().item() + 1e-3
+
+
+def test_gemm_router_takes_misaligned_views():
+    """nnops.gemm on views whose base is only 2-byte aligned / whose row stride is odd: the any-shape kernel, right answer."""
+    from kvq import nnops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    big_a = torch.randn((130, 200), generator=g, device="cuda").to(torch.bfloat16)
+    big_b = torch.randn((96, 203), generator=g, device="cuda").to(torch.bfloat16)
+    a, b = big_a[:, 3:131], big_b[:, 1:129]                    # [130, 128] and [96, 128], misaligned
+    assert not nnops.gemm_mfma_ok(a, b, None, "nt")
+    out = nnops.gemm(a, b, "nt")
+    ref = a.float() @ b.float().t()
+    assert (out.float() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-3
+
+
+def test_pick_tile_rule():
+    """The rule that replaced the engine's exact-shape tables: at the benchmarked 8192 rows it reproduces the measured choices;
+    at the reference's own row counts (12 tokens x 64 / 128 sentences) it turns to the small tile."""
+    from kvq import nnops
+    name = lambda M, N: nnops.TILE_NAMES[nnops.pick_tile(M, N)]
+    assert name(8192, 768) == "128x192" and name(8192, 3072) == "256x192" and name(8192, 18432) == "256x256" and name(8192, 30528) == "256x256"
+    assert name(768, 768) == "64x128" and name(1536, 768) == "64x128"

@@ -403,9 +403,10 @@ def test_attention_above_32_tokens_dropout_mask_consistency(ops):
 
 @pytest.mark.parametrize("amsgrad,wd", [(False, 0.0), (True, 0.01)])
 @pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
-def test_adam_matches_torch(ops, amsgrad, wd, gdtype):
+@pytest.mark.parametrize("n", [4096 * 3, 9, 4 * 5 + 3, 2])
+def test_adam_matches_torch(ops, amsgrad, wd, gdtype, n):
+    """(n = 9: the bias of the reference analysis' 9-code Gumbel projection; sizes that are not multiples of 4 take the scalar tail)"""
     torch.manual_seed(1)
-    n = 4096 * 3
     p = torch.randn(n, device="cuda")
     ref_p = p.clone().requires_grad_(True)
     opt = torch.optim.Adam([ref_p], lr=1e-3, weight_decay=wd, amsgrad=amsgrad)
