@@ -308,7 +308,9 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
     const int cbase = code0 + w * 32;
     float* e2s = smem + T2_WAVES * 2 * TMW + 32 * w;          // behind the merge buffers; 32 floats per wave (z stages are dead)
     unsigned long long* red_key = reinterpret_cast<unsigned long long*>(smem);     // [4 waves][TMW]
-    if (lane < 32) e2s[i] = e2v;                              // (same wave writes and reads: LDS operations of a wave stay in order)
+    if (lane < 32) e2s[i] = e2v;                              // same wave writes and reads: LDS operations of a wave stay in order in
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // hardware; the fence + wave barrier pin that order for the compiler as
+    __builtin_amdgcn_wave_barrier();                          // well (no instruction is emitted for either)
     f32x4 e2q[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) e2q[q] = *reinterpret_cast<const f32x4*>(e2s + 8 * q + 4 * h);

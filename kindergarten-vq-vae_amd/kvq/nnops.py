@@ -75,6 +75,9 @@ def embed_ln_fwd(ids, word, pos, type_row, gamma, beta, eps, seq_len, p_drop=0.0
     Returns (out, pre, mean, rstd) like ln_fwd; ids flat int64 [N]."""
     require_gpu(ids, word, pos)
     N, H = ids.numel(), word.shape[1]
+    if pos.shape[0] < seq_len or N % seq_len != 0:      # the kernel reads pos[(n % seq_len)]: rows that must exist
+        raise KvqError(f"kvq.nnops.embed_ln_fwd: {N} ids in sentences of {seq_len} tokens need {seq_len} position rows "
+                       f"(the table has {pos.shape[0]}) and a whole number of sentences")
     out = torch.empty((N, H), dtype=word.dtype, device=word.device)
     pre = torch.empty_like(out)
     mean = torch.empty(N, dtype=torch.float32, device=word.device)

@@ -311,3 +311,79 @@ def test_ranks_bf16_bert_base_shapes_equal_single_process(tmp_path, world):
     for tag in ("eager", "graph"):
         for step in BASE_CHECK:
             assert abs(rep[(tag, step, "loss")] - ref_loss[step]) < 0.5, (tag, step)     # rank 0 sees its half only: same scale
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# The data-parallel INVARIANT at the shapes configs[2] runs, with the optimiser moving: after every step all ranks
+# hold bit-identical averaged gradients, master weights, bf16 shadow weights, Adam moments and codebook -- whatever the rounding,
+# since every rank applies the same update to the same average.  It needs no single-process oracle, so lr can be what training
+# uses.  This is the check of _exchange_head / _exchange_tail + the Adam launches that start on the tail of the buffer while its
+# head is still being reduced: a chunk updated before its average arrived, or reduced twice, differs between the ranks (each
+# rank trains on a DIFFERENT half batch).
+# ----------------------------------------------------------------------------------------------------------------------------
+MOVE_STEPS, MOVE_LR = 4, 1e-4
+
+
+def _identical_across_ranks(t):
+    """True iff the tensor's bits are the same on every rank (max == min over the ranks, elementwise on the raw 32-bit words)."""
+    import torch.distributed as dist
+    raw = t.detach().contiguous().view(torch.int16 if t.element_size() == 2 else torch.int32).to(torch.int32)
+    hi, lo = raw.clone(), raw.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return bool(torch.equal(hi, lo))
+
+
+def _worker_moving(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    import torch.distributed as dist
+    from kvq import ddp
+    from kvq.engine import TrainEngine
+    torch.cuda.set_device(0)
+    ddp.init_distributed("gloo")
+    ids, mask = _data_base(world)
+    half = slice(rank * 64, rank * 64 + 64)
+    report = {}
+    for tag, use_graph in (("eager", False), ("graph", True)):
+        model = _build_base()                       # eval mode: dropout off (each rank would draw its own masks anyway)
+        ddp.broadcast_parameters(model)
+        eng = TrainEngine(model, lr=MOVE_LR, bucket_mib=4)
+        eng.use_graph = use_graph
+        assert eng.world == world and eng._dp and eng._own_wgrad
+        start = eng.flat.master.clone()
+        for step in range(1, MOVE_STEPS + 1):
+            res = eng.train_step(ids[half], mask[half])
+            torch.cuda.synchronize()
+            same = {"grad": _identical_across_ranks(eng.flat.grad), "master": _identical_across_ranks(eng.flat.master),
+                    "shadow": _identical_across_ranks(eng.flat.shadow), "codebook": _identical_across_ranks(eng.E.data),
+                    "codebook_grad": _identical_across_ranks(eng.gE)}
+            if step == MOVE_STEPS:
+                same.update(m=_identical_across_ranks(eng.flat.m), v=_identical_across_ranks(eng.flat.v),
+                            aux_m=all(_identical_across_ranks(a["m"]) for a in eng.aux),
+                            aux_v=all(_identical_across_ranks(a["v"]) for a in eng.aux))
+            report[(tag, step)] = same
+            report[(tag, step, "loss")] = float(res["loss_recon"])
+        report[tag + "_moved"] = float((eng.flat.master - start).abs().max())
+        report[tag + "_codebook_moved"] = float(eng.aux[0]["m"].abs().max())          # first Adam moment of the codebook: nonzero once it moved
+        if use_graph:
+            assert len(eng._graphs) == 1
+        del eng, model
+        torch.cuda.empty_cache()
+    if rank == 0:
+        torch.save(report, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_bf16_optimizer_moves_and_the_ranks_stay_bit_identical(tmp_path):
+    out = str(tmp_path / "dp_move.pt")
+    mp.spawn(_worker_moving, args=(2, _free_port(), out), nprocs=2, join=True)
+    rep = torch.load(out)
+    for tag in ("eager", "graph"):
+        assert rep[tag + "_moved"] > 1e-5 and rep[tag + "_codebook_moved"] > 0, "the optimiser did not move anything"
+        for step in range(1, MOVE_STEPS + 1):
+            bad = [k for k, ok in rep[(tag, step)].items() if not ok]
+            assert not bad, f"{tag} step {step}: ranks differ in {bad}"
+        losses = [rep[(tag, s, "loss")] for s in range(1, MOVE_STEPS + 1)]
+        assert all(l == l for l in losses) and losses[-1] < losses[0], losses
