@@ -284,7 +284,7 @@ int kvq_attn_set_variant(int variant);
  *   KVQ_GEMM_TN  C[M,N] = A[K,M]^T . B[K,N]     weight gradient (gy, x)       autograd: grad_output.t().mm(input)
  * bf16 operands and result, f32 accumulation (v_mfma_f32_16x16x32_bf16), optional bias[N] (bf16) and C += (accumulate != 0).
  * K %% 64 == 0; M, N, lda, ldb, ldc %% 8 == 0; 16-byte aligned operands; row-major with the given leading dimensions.
- * `tile` picks the workgroup tile: the caller chooses it so that the tile count fills the 256 CUs.
+ * `tile` picks the workgroup tile: the caller chooses it so that the tile count fills the 256 CUs (kvq.nnops.pick_tile is the caller's rule).
  * A grouped launch runs up to 16 problems of ONE layout as a single grid (e.g. the weight gradients of two BERT layers:
  * ~250 tiles of 256 x 256, one per CU over the whole token contraction -- no split-K, no partial slabs). */
 #define KVQ_GEMM_NT 0
@@ -298,7 +298,7 @@ int kvq_attn_set_variant(int variant);
                                    * batches: 12 tokens x 64..128 sentences, models/shelgon3/Trainer.py:82) */
 /* OR-ed into `tile` (layout NT, one problem, no accumulate, M and N at least one tile, K >= 192): the PERSISTENT form -- one
  * workgroup per CU walks its tiles, the k-tiles of successive tiles form one uninterrupted LDS-DMA stream and the epilogue
- * goes from the accumulator registers straight to memory; pays when a CU owns two or more tiles (DESIGN.md section 2.3). */
+ * goes from the accumulator registers straight to memory; pays when a CU owns two or more tiles (DESIGN.md §2.2). */
 #define KVQ_GEMM_PERSISTENT 0x100
 typedef struct kvq_gemm_problem {
     const void* A;

@@ -14,7 +14,7 @@
 //                                              the MFMA wants 8 consecutive k per lane, memory has them 2*ld bytes apart),
 //                                              32-byte segments XORed with ((k>>1)&1) | ((k>>3)&1)<<1
 //     both swizzles are applied on the DMA's per-lane SOURCE address (its LDS destination is lane-linear) and undone by the
-//     reads; both are bank-conflict free for their read instruction (derivation in DESIGN.md §2.3).
+//     reads; both are bank-conflict free for their read instruction (derivation in profiles/NOTES_r01-r03_design_and_experiments.md §2.3).
 //   * one raw s_barrier per k-tile; the DMA of tile kt+NS is issued right behind the barrier that frees its slot and is waited
 //     for NS-1 tiles later with a COUNTED s_waitcnt vmcnt (never 0 inside the loop): NS-1 tiles stay in flight per CU.
 //   * every wave software-pipelines itself: the fragments of k-step s+1 are read from LDS while the MFMAs of k-step s run

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
     // indices past the row are clamped (and masked out of the sums), a missing residual reads y again and is weighted 0.
     // As first written ("if (c < nchunk) { load y; ...; if (resid) load resid; ... }" per chunk) hipcc put s_waitcnt vmcnt(0)
     // behind each load: six dependent trips to memory per row, then three more for gamma / beta -- 13.3 us for the 50 MB of a
-    // [8192, 768] call, one round of waves doing nothing but waiting (ISA audit of round 3).
+    // [8192, 768] call, one round of waves doing nothing but waiting (ISA audit of round 3, profiles/NOTES_r01-r03_design_and_experiments.md section 2.5).
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;

@@ -695,7 +695,7 @@ class TrainEngine:
     def _flush_wgrads(self, force=True):
         """The weight gradients queued so far as grouped launches, written straight into the flat bf16 gradient buffer, each
         tile contracting over all tokens (no split-K).  The kernel's rate is set by bytes staged per flop (the L2 -> LDS fill
-        is the limit, DESIGN.md §2.3), so the 256 x 256 tile is the fast one -- but one BERT layer is only 108-126 of them.  The
+        is the limit, DESIGN.md §2.2), so the 256 x 256 tile is the fast one -- but one BERT layer is only 108-126 of them.  The
         queue is therefore held (force=False) until TWO layers' worth is there: 216-252 tiles = one round of the 256 CUs.
         Returns True when nothing is left queued."""
         items = self._wg_items

@@ -325,7 +325,7 @@ def pick_tile(M, N, K=768, n_cu=256, candidates=None):
 
 def persistent_pays(t, M, N, K, layout, accumulate=False, n_cu=256):
     """The persistent tile loop (KVQ_GEMM_PERSISTENT: NT only, whole tiles, no accumulate) instead of one tile per workgroup:
-    when a CU owns 3 .. 12 tiles.  Measured at 8192 rows (tools/gemm2_probe_persist.py): QKV (3 tiles per CU)
+    when a CU owns 3 .. 12 tiles.  Measured at 8192 rows (tools/gemm2_probe_persist.py, profiles/NOTES_r01-r03_design_and_experiments.md section 2.3): QKV (3 tiles per CU)
     and the all-layer cross-K/V projection (9) gain 1 - 4 %, two tiles per CU (FFN1) lose, the LM head (15, column bands) loses 6 %."""
     bm, bn = _TILE_DIMS[t]
     if layout != "nt" or accumulate or t == 4 or M < bm or N < bn or K // 64 < 3:
