@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
 # same-box A/B of the XCD-aware (sentence, head) order of the attention kernels:  gpurun -- bash tools/ab_attn_xcd.sh
+# (the KVQ_ATTN_XCD switch was removed after this measurement: profiles/r04_rejected.md)
 set -uo pipefail
 out=gpurun_out/r4j; mkdir -p "$out"
 for i in 1 2 3; do

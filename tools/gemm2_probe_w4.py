@@ -2,7 +2,9 @@
 """256 x 256 tile with FOUR waves (one per SIMD, 128 x 128 per wave: 0.5 LDS fragment reads per MFMA instead of 0.75) against the
 eight-wave 256 x 256 and 128 x 256 tiles, on the products of the step that run 256-wide tiles: weight gradients (TN, contraction
 over 8192 tokens; single and grouped launches of two layers), LM head and all-layer cross-K/V forward (NT), LM-head input gradient
-(NN).  Interleaved rounds, one process.  usage: gemm2_probe_w4.py [rounds]"""
+(NN).  Interleaved rounds, one process.  (The "256x256w4" tile was removed after this measurement -- profiles/r04_rejected.md; re-add `Cfg<256, 256, 2, 2, AK, BKM, 2>` as
+a tile of csrc/kvq_gemm2.hip to run the probe again.)
+usage: gemm2_probe_w4.py [rounds]"""
 import os
 import sys
 
