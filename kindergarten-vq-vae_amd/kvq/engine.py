@@ -505,8 +505,15 @@ class TrainEngine:
                 raise KvqError("TrainEngine: the Gumbel row kernel holds at most 1024 codes")
             self.g_pw, self.g_pb, self.g_emb = add_aux(gq.proj.weight), add_aux(gq.proj.bias), add_aux(gq.embed.weight)
         # extension (BASELINE.json configs[4], default off): forward GEMMs on the fp8 matrix cores; per-tensor scales -- weights from
-        # the tensor itself after every update, activations delayed by one training step (kvq_fp8_quantize_delayed)
-        self.fp8 = (os.environ.get("KVQ_FP8", "0") == "1") if fp8_forward is None else bool(fp8_forward)
+        # the tensor itself after every update, activations delayed by one training step (kvq_fp8_quantize_delayed).
+        # True / KVQ_FP8=1: the products where fp8 + the activation's quantisation pass beat the own bf16 kernel -- outputs at least
+        # _FP8_MIN_ROWS wide: the LM head and the all-layer cross-K/V projection (tools/gemm2_probe_fp8_own.py, profiles/r04_fp8.md:
+        # 292 against 350 us and 184 against 217; every per-layer GEMM LOSES 4 - 8 us to its quantisation pass).
+        # "all" / KVQ_FP8=all: every forward GEMM (rounds 2 - 3; kept for the numerics tests and as the A/B arm).
+        if fp8_forward is None:
+            fp8_forward = {"0": False, "1": True, "all": "all"}.get(os.environ.get("KVQ_FP8", "0"), False)
+        self.fp8 = bool(fp8_forward)
+        self._fp8_all = fp8_forward == "all"
         if self.fp8:
             if self.dtype != torch.bfloat16:
                 raise KvqError("TrainEngine: fp8 forward GEMMs need the bf16 compute dtype")
@@ -568,6 +575,8 @@ class TrainEngine:
     _TILE_OVERRIDE: Dict[Tuple[int, int], str] = {}
 
     # ---- fp8 forward GEMMs -------------------------------------------------------------------------------------------------
+    _FP8_MIN_ROWS = 8192          # output width from which fp8 + its quantisation pass beat the bf16 kernel (see __init__)
+
     def _fp8_setup(self):
         """One fp8 mirror of the flat bf16 shadow buffer; one quantisation segment (= one scale) per forward GEMM weight: the
         fused q|k|v block, the all-layer cross-attention k|v block, every other [out, in] matrix, the padded LM-head table."""
@@ -577,7 +586,11 @@ class TrainEngine:
         def seg(key, names, rows=None):
             o0 = fl.seg[names[0]][0]
             n = sum(fl.seg[nm][1] for nm in names) if rows is None else rows * fl.seg[names[0]][2][1]
-            segs[key] = (o0, n)
+            only = os.environ.get("KVQ_FP8_ONLY")          # diagnostic: "all" restricted to weights whose name contains one of these
+            if only and not any(t in key for t in only.split(",")):
+                return
+            if self._fp8_all or n // fl.seg[names[0]][2][1] >= self._FP8_MIN_ROWS:
+                segs[key] = (o0, n)
         for i in range(self.n_enc_layers):
             pre = f"enc.{i}."
             seg(pre + "sa.q.w", [pre + "sa.q.w", pre + "sa.k.w", pre + "sa.v.w"])
@@ -595,6 +608,9 @@ class TrainEngine:
         seg("head.t.w", ["head.t.w"])
         seg("dec.emb.word", ["dec.emb.word"], rows=self.Vp)
         keys = list(segs)
+        if not keys:
+            raise KvqError("TrainEngine: fp8 forward GEMMs asked for, but no weight of this model is wide enough for them to pay "
+                           f"(>= {self._FP8_MIN_ROWS} rows); use fp8_forward=\"all\" to put every forward GEMM on fp8")
         self._w8_index = {k: i for i, k in enumerate(keys)}
         offs = [segs[k][0] for k in keys]
         ns = [segs[k][1] for k in keys]
@@ -663,7 +679,7 @@ class TrainEngine:
         """Tile of the fused-activation GEMMs (they exist for 256 x 192 and 128 x 256), or None when the plain GEMM on its best
         tile + the separate activation kernel (one pass over [M, N]: ~3 us + 4 bytes per element at ~3 TB/s) is modelled cheaper --
         outputs too small to give half the CUs one of the large tiles."""
-        if not (self._own_fwd and self._own_epi and self.dtype == torch.bfloat16 and not self.fp8):
+        if not (self._own_fwd and self._own_epi and self.dtype == torch.bfloat16):
             return None
         t = nnops.pick_tile(M, N, K, candidates=("256x192", "128x256"))
         plain = nnops.tile_cost_us(nnops.pick_tile(M, N, K), M, N, K) + 3.0 + M * N * 4 / 3e6
@@ -672,7 +688,8 @@ class TrainEngine:
     def _linear_gelu(self, x, wname, bname):
         """(h, gelu(h)), h = x . W^T + b: one kernel where the own GEMM carries the activation in its epilogue."""
         W, b = self.flat.w(wname), self.flat.w(bname)
-        tile = self._epilogue_tile(x.shape[0], W.shape[0], W.shape[1])
+        on_fp8 = self.fp8 and wname in self._w8_index         # (fp8 "all": the fp8 GEMM has no activation epilogue)
+        tile = None if on_fp8 else self._epilogue_tile(x.shape[0], W.shape[0], W.shape[1])
         if tile is not None and x.is_contiguous() and nnops.gemm_mfma_ok(x, W, None, "nt", b):
             return nnops.gemm_gelu(x, W, b, tile=tile)
         h = self._linear(x, wname, bname)

@@ -60,8 +60,10 @@ def _build(seed=0):
     return Shelgon("kvq-bert-base-2l", vq, "kvq-bert-base-2l", None, compute_dtype=torch.bfloat16).cuda().eval()
 
 
-def test_engine_fp8_forward_against_the_bf16_engine():
-    """bert-base widths, 2 layers, 2048 tokens: every forward GEMM on the fp8 matrix cores, backward in bf16.
+@pytest.mark.parametrize("scope", ["all", True])
+def test_engine_fp8_forward_against_the_bf16_engine(scope):
+    """bert-base widths, 2 layers, 2048 tokens: forward GEMMs on the fp8 matrix cores -- every one ("all") or, the default of
+    fp8_forward=True, the two that pay for their quantisation pass (LM head, all-layer cross-K/V) --, backward in bf16.
     Stated tolerance: reconstruction loss within 2e-2 relative of the bf16 engine, VQ loss within 5e-2; gradients point the
     same way (cosine > 0.9 per tensor, > 0.98 on average)."""
     from dsentences.synthetic import random_token_batch
@@ -70,7 +72,7 @@ def test_engine_fp8_forward_against_the_bf16_engine():
     runs = {}
     for fp8 in (False, True):
         model = _build()
-        eng = TrainEngine(model, lr=1e-4, fp8_forward=fp8)
+        eng = TrainEngine(model, lr=1e-4, fp8_forward=scope if fp8 else False)
         out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
         grads = {n: eng.flat.g(n).float().clone() for n, p in eng.param_of.items() if p.requires_grad}
         runs[fp8] = (out["loss_recon"].item(), out["loss_vq"].item(), out["indices"].clone(), grads, eng)
@@ -81,8 +83,12 @@ def test_engine_fp8_forward_against_the_bf16_engine():
     cos = [F.cosine_similarity(g1[n].reshape(-1), g0[n].reshape(-1), dim=0).item() for n in g0 if g0[n].norm() > 0 and not n.endswith("k.b")]
     assert min(cos) > 0.9 and np.mean(cos) > 0.98, (min(cos), np.mean(cos))
     # the weight mirror: every segment is the torch conversion of the bf16 shadow at that segment's own scale
-    key = "enc.0.f1.w"
+    # (two decoder layers: the all-layer cross-K/V block is 3072 rows, below the width from which fp8 pays; at 12 layers it is 18432)
+    assert ("enc.0.f1.w" in e8._w8_index) == (scope == "all") and "dec.emb.word" in e8._w8_index
+    assert (e8._cakv_w[0] in e8._w8_index) == (scope == "all")
+    key = "enc.0.f1.w" if scope == "all" else "dec.emb.word"
     si, (o, n, shape) = e8._w8_index[key], e8.flat.seg[key]
+    n = e8._w8_n[si].item()
     want, s = _ref_quant(e8.flat.shadow[o:o + n])
     np.testing.assert_allclose(e8._w8_scale[si].item(), s, rtol=1e-6)
     assert torch.equal(e8._w8[o:o + n].cpu().view(torch.float8_e4m3fn).float(), want.float())

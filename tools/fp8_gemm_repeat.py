@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Does the fp8 GEMM give the same bits every time?  (fp8 "all" runs of bench.py ended at different losses after 35 steps.)  Every
+forward shape of the step, 300 launches each on the same operands, compared bitwise with the first; the same for the delayed
+quantisation pass and for a bf16 GEMM as control."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+import torch  # noqa: E402
+from kvq import nnops  # noqa: E402
+from kvq._ffi import check, lib, stream_ptr  # noqa: E402
+
+dev, T = "cuda", 8192
+g = torch.Generator(device=dev).manual_seed(0)
+for n, k in [(768, 768), (2304, 768), (3072, 768), (768, 3072), (18432, 768), (30528, 768)]:
+    x = torch.randn((T, k), device=dev, generator=g).to(torch.bfloat16)
+    w = torch.randn((n, k), device=dev, generator=g).to(torch.bfloat16)
+    b = torch.randn(n, device=dev, generator=g).to(torch.bfloat16)
+    x8, sx = nnops.fp8_quantize(x)
+    w8, sw = nnops.fp8_quantize(w)
+    first = nnops.gemm_fp8_nt(x8, w8, sx, sw, bias=b).clone()
+    bad = 0
+    out = torch.empty_like(first)
+    for i in range(300):
+        nnops.gemm_fp8_nt(x8, w8, sx, sw, bias=b, out=out)
+        if i % 10 == 9 and not torch.equal(out, first):
+            bad += 1
+    st = torch.zeros(lib().kvq_fp8_state_floats(), dtype=torch.float32, device=dev)
+    st[0] = 3.0
+    q0 = torch.empty((T, k), dtype=torch.uint8, device=dev)
+    check(lib().kvq_fp8_quantize_delayed(x.data_ptr(), T, k, k, q0.data_ptr(), st.data_ptr(), stream_ptr()), "q")
+    qbad = 0
+    q1 = torch.empty_like(q0)
+    for i in range(50):
+        check(lib().kvq_fp8_quantize_delayed(x.data_ptr(), T, k, k, q1.data_ptr(), st.data_ptr(), stream_ptr()), "q")
+        qbad += not torch.equal(q0, q1)
+    ref = nnops.gemm(x, w, "nt", bias=b).clone()
+    cbad = sum(not torch.equal(nnops.gemm(x, w, "nt", bias=b), ref) for _ in range(30))
+    print(f"N={n:6d} K={k:5d}: fp8 GEMM mismatching checks {bad}/30, quantise {qbad}/50, bf16 control {cbad}/30", flush=True)
