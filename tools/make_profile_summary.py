@@ -14,7 +14,7 @@ shutil.copy(stats, f"profiles/{tag}_step_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = [f"# {tag} profile summaries (1x MI355X, rocprofv3, ROCm 7.2)", "",
-       "## Training step: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 10 --warmup 3`",
+       "## Training step: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 --family-steps 0`",
        f"{steps} steps traced (3 warm-up + 10 timed); total kernel time {tot/1e6:.1f} ms = {tot/1e6/steps:.2f} ms/step "
        f"(sum of kernel durations under the profiler; the un-profiled wall-clock step of the same recipe is in `profiles/{tag}_bench_line.json`). Full CSV: `profiles/{tag}_step_kernel_stats.csv`.", "",
        "| kernel | calls | ms/step | avg us | % |", "|---|---|---|---|---|"]
@@ -80,6 +80,6 @@ if dk:
                  "forward_kernels_N8192_K8192_D768_bfloat16": {k: traffic8[k] for k in traffic8 if any(t in k for t in ("dist_packed", "vq_epilogue", "vq_finalize"))}}
     json.dump({"N8192_K512_D768_bfloat16": traffic[dk[0]], "_kernel": dk[0], "forward_kernels_N8192_K512_D768_bfloat16": fwd, **extra,
                "_source": f"profiles/{tag}_summary.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
-                          f"launch; the factor 2 on FETCH_SIZE holds for 4-, 8- and 16-byte loads per lane alike (calibration in profiles/{tag}_gemm_pmc.md)"},
+                          f"launch; the factor 2 on FETCH_SIZE holds for 4-, 8- and 16-byte loads per lane alike (calibration: profiles/r02_gemm_pmc.md, confirmed in r03_gemm_memsys.md)"},
               open("profiles/vq_fwd_traffic.json", "w"), indent=1)
 print("\n".join(out[-14:]))
