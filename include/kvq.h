@@ -115,6 +115,9 @@ int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int 
  *   kvq_prof_read(ms, max) : after the caller has synchronised the stream, writes up to `max` durations in
  *                            milliseconds (oldest first), clears the ring and returns how many were written. */
 int kvq_prof_enable(int n_pairs);
+/* hipGraph note (ROCm 7.2): kvq_vq_forward / kvq_vq_forward_packed / kvq_vq_ema_update clear small accumulators with hipMemsetAsync.
+ * Launch them eagerly (the TrainEngine does: "interludes" between its graphs); a memset captured as a graph node was observed not to
+ * keep its stream order ahead of the next kernel node (profiles/r04_fp8.md).  Every other entry point launches kernels only. */
 int kvq_prof_read(float* ms_host, int max);
 
 /* Clock probe (measurement aid of bench.py; no reference counterpart): every one of kvq_clock_probe_rows() single-wave workgroups

@@ -62,6 +62,14 @@ __device__ __forceinline__ void block_amax_to(float m, float* dst) {
 
 __device__ __forceinline__ float scale_of(float amax) { return amax > 0.f ? FP8_MAX / amax : 1.0f; }
 
+// amax accumulators are zeroed by a KERNEL, not hipMemsetAsync: a memset captured into a hipGraph is a node of another kind and
+// was the one thing in the replayed fp8 step that did not keep its place in the stream's order -- with 123 segments two identically
+// seeded runs parted ways after 8 - 14 steps (an amax cleared after the first maxima had landed), eager launches never did
+// (tools/fp8_flake.py, profiles/r04_fp8.md)
+__global__ __launch_bounds__(256) void fp8_zero_kernel(float* __restrict__ p, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0.f;
+}
+
 // segments: seg s covers elements [off[s], off[s] + n[s]) of src (bf16) / dst (fp8), n[s] % 8 == 0, off[s] % 8 == 0
 __global__ __launch_bounds__(Q_THREADS) void fp8_seg_amax_kernel(const unsigned short* __restrict__ src, const int64_t* __restrict__ off,
                                                                   const int64_t* __restrict__ n, float* __restrict__ amax) {
@@ -185,8 +193,7 @@ int kvq_fp8_quantize(const void* x_bf16, int64_t rows, int cols, int64_t ld, voi
     KVQ_REQUIRE(cols % 8 == 0 && ld % 8 == 0 && ld >= cols && (((uintptr_t)x_bf16 | (uintptr_t)out_fp8) & 15) == 0,
                 "kvq_fp8_quantize: cols, ld multiples of 8 and 16-byte aligned buffers");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), st);
-    if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(fp8_zero_kernel, dim3(1), dim3(256), 0, st, amax, 1);
     const int64_t chunks = rows * (cols / 8);
     const unsigned grid = (unsigned)((chunks + Q_THREADS * 4 - 1) / (Q_THREADS * 4) > 2048 ? 2048 : (chunks + Q_THREADS * 4 - 1) / (Q_THREADS * 4));
     hipLaunchKernelGGL(fp8_amax_kernel, dim3(grid), dim3(Q_THREADS), 0, st, (const unsigned short*)x_bf16, rows, cols, ld, amax);
@@ -217,8 +224,7 @@ int kvq_fp8_quantize_segments(const void* src_bf16, const int64_t* seg_off, cons
     KVQ_REQUIRE(src_bf16 && seg_off && seg_n && dst_fp8 && amax && scale && nseg > 0 && max_seg_n > 0, "kvq_fp8_quantize_segments: bad argument");
     KVQ_REQUIRE((((uintptr_t)src_bf16 | (uintptr_t)dst_fp8) & 15) == 0, "kvq_fp8_quantize_segments: 16-byte aligned buffers");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(amax, 0, (size_t)nseg * sizeof(float), st);
-    if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(fp8_zero_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, amax, nseg);
     const int64_t chunks = max_seg_n / 8;
     unsigned gx = (unsigned)((chunks + Q_THREADS * 8 - 1) / (Q_THREADS * 8));
     gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);

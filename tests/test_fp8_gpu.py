@@ -137,3 +137,41 @@ def test_fp8_forward_with_the_nine_factor_quantiser_at_bert_base_widths():
     e8.model.train()
     losses = [float(e8.train_step(ids, mask)["loss_recon"]) for _ in range(8)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0] and e8._graphs, losses
+
+
+def test_weight_quantisation_replayed_from_a_graph_equals_eager():
+    """kvq_fp8_quantize_segments inside a captured hipGraph, replayed on changing weights: scales and bytes equal the eager call every
+    time.  Regression test of round 4's finding: the amax accumulators used to be cleared by hipMemsetAsync, and a memset node of a
+    replayed graph did not keep its place ahead of the amax kernel -- with 123 segments (every forward GEMM on fp8) two identically
+    seeded training runs parted ways after 8 - 14 steps (tools/fp8_flake.py); a kernel clears them now."""
+    from kvq._ffi import check, lib, stream_ptr
+    nseg, seg_n = 128, 768 * 768
+    g = torch.Generator(device="cuda").manual_seed(0)
+    src = torch.randn(nseg * seg_n, device="cuda", generator=g).to(torch.bfloat16)
+    off = (torch.arange(nseg, device="cuda", dtype=torch.int64) * seg_n)
+    n = torch.full((nseg,), seg_n, device="cuda", dtype=torch.int64)
+    dst = torch.zeros(nseg * seg_n, dtype=torch.uint8, device="cuda")
+    amax = torch.zeros(nseg, device="cuda")
+    scale = torch.ones(nseg, device="cuda")
+
+    def quantise():
+        check(lib().kvq_fp8_quantize_segments(src.data_ptr(), off.data_ptr(), n.data_ptr(), nseg, seg_n, dst.data_ptr(), amax.data_ptr(),
+                                              scale.data_ptr(), stream_ptr()), "kvq_fp8_quantize_segments")
+    quantise()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        quantise()
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    base = src.clone()
+    for it in range(40):
+        src.copy_(base * (0.01 if it % 2 else 3.0) * (1.0 + 0.1 * (it % 5)))      # every replay sees other maxima than the one before
+        graph.replay()
+        got_scale, got = scale.clone(), dst.clone()
+        quantise()                                                                   # eager, same stream: the truth
+        assert torch.equal(scale, got_scale), f"replay {it}: {(scale != got_scale).sum().item()} of {nseg} scales differ from the eager call"
+        assert torch.equal(dst, got), f"replay {it}: quantised bytes differ"
