@@ -1689,12 +1689,20 @@ class TrainEngine:
         none = dict(pack=None, enc=None, dec=None)
         if prepared is None:
             return none
+        def pair(t, ids, what):
+            if t is None:
+                return None
+            if not isinstance(t, (tuple, list)) or len(t) != 2 or any(not torch.is_tensor(x) or x.numel() != ids.numel() or x.dtype != torch.int64
+                                                                      for x in t):
+                raise KvqError(f"TrainEngine: prepared {what} = (sorted ids, order) must be prepare_batch() of this call's {what} ids")
+            return (t[0].reshape(-1), t[1].reshape(-1))
         if isinstance(prepared, dict):
-            return dict(none, **{k: prepared.get(k) for k in ("enc", "dec")})
+            if prepared.get("dec") is not None and dec_ids is None:
+                raise KvqError("TrainEngine: prepared holds a decoder side but the call passes no dec_ids")
+            return dict(none, enc=pair(prepared.get("enc"), input_ids, "encoder"),
+                        dec=pair(prepared.get("dec"), dec_ids, "decoder") if dec_ids is not None else None)
         if isinstance(prepared, (tuple, list)):
-            if len(prepared) != 2 or any(not torch.is_tensor(t) or t.numel() != input_ids.numel() for t in prepared):
-                raise KvqError("TrainEngine: prepared=(sorted ids, order) must be prepare_batch() of this call's input_ids")
-            return dict(none, enc=(prepared[0].reshape(-1), prepared[1].reshape(-1)))
+            return dict(none, enc=pair(prepared, input_ids, "encoder"))
         if not torch.is_tensor(prepared):
             raise KvqError(f"TrainEngine: prepared must be pack_batch()'s tensor or prepare_batch()'s tuple, got {type(prepared).__name__}")
         ids, mask, srt, perm, dec = self.unpack_batch(prepared, input_ids.shape, dec_ids.shape if dec_ids is not None else None)

@@ -252,3 +252,30 @@ def test_engine_refuses_mismatched_decoder_inputs():
         eng.forward_backward(e, em, dec_ids=d)                                # no mask
     with pytest.raises(KvqError):
         eng.forward_backward(e, em, dec_ids=d, dec_mask=dm, target_ids=d[:, :5])
+
+
+def test_bagon_engine_with_different_encoder_and_decoder_stacks():
+    """The reference builds encoder and decoder from two names (models/bagon/Bagon.py:16-31; its main.py even allows a GPT-2 decoder
+    tokenizer): here a 2-layer / 2048-word encoder feeds a 1-layer / 512-word / 32-position decoder (equal hidden width, which
+    cross-attention needs).  Engine (f32) against autograd through HuggingFace's forward, two-sided ids, every parameter."""
+    from kvq.engine import TrainEngine
+    from models.bagon.Bagon import Bagon
+    torch.manual_seed(0)
+    model = Bagon("kvq-bert-tiny", "kvq-bert-fixture", True, compute_dtype=torch.float32).cuda().eval()
+    assert model.encoder.config.vocab_size != model.decoder.config.vocab_size
+    assert model.encoder.config.num_hidden_layers != model.decoder.config.num_hidden_layers
+    e, em, _, _ = _two_sided_batch(B=5, S=12, seed=9, lo=1000, hi=2000)
+    _, _, d, dm = _two_sided_batch(B=5, S=10, seed=9, lo=100, hi=500)
+    eng = TrainEngine(model, lr=1e-3)
+    out = eng.forward_backward(e, em, training=False, compute_grads=True, dec_ids=d, dec_mask=dm)
+    mine = _engine_grads(eng, model)
+    ref = _hf_autograd(model, e, em, d, dm)
+    np.testing.assert_allclose(out["loss_recon"].item(), ref["loss"], rtol=2e-5)
+    assert torch.equal(out["recon_ids"], ref["recon"]) and set(mine) == set(ref["grads"])
+    for n, g in mine.items():
+        if not n.endswith("key.bias"):
+            assert _rel(g, ref["grads"][n]) < 2e-3, f"{n}: relative L2 error {_rel(g, ref['grads'][n]):.3g}"
+    # and it trains through the replayed graphs
+    model.train()
+    losses = [float(eng.train_step(e, em, dec_ids=d, dec_mask=dm)["loss_recon"]) for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] and eng._graphs, losses
