@@ -13,6 +13,8 @@
 // keyed by (seed, site) and indexed by the element position.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "kvq_common.h"
 #include <type_traits>
 
@@ -1787,6 +1789,33 @@ __device__ __forceinline__ void load_row_chunks(const void* base, size_t row_off
         f[s].x = t.x & m; f[s].y = t.y & m; f[s].z = t.z & m; f[s].w = t.w & m;
     }
 }
+// The same row chunks, fetched in WHOLE cache lines: wave-instruction j reads rows 8j .. 8j + 7 of the (sentence, head) operand,
+// eight lanes per row, 16 bytes per lane -- eight full 128-byte lines per instruction.  load_row_chunks() asks for 32 bytes of each
+// of 32 lines per instruction and comes back to every line four times; with 12 waves x 4 operands x 4 KiB in flight per CU those
+// lines do not survive in the 32-KiB vector cache, so most of them travel from L2 more than once.  rows_to_chunks() then moves
+// the data to the lanes the MFMA operands want it on (lane (r, h): chunks h, 2 + h, 4 + h, 6 + h of row r) through a 32 x 144-byte
+// LDS image -- the 4608 bytes of the kernel's pair-interleaved tile, before that tile is used for anything else.
+__device__ __forceinline__ void load_rows_coalesced(const void* base, size_t row0_off, int ld, int S, int lane, uint4 (&g)[4]) {
+    const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + row0_off + 8 * (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * j + (lane >> 3);
+        const unsigned m = row < S ? 0xffffffffu : 0u;
+        const uint4 t = *reinterpret_cast<const uint4*>(p + (size_t)(row < S ? row : S - 1) * ld);      // clamped, never branched around
+        g[j].x = t.x & m; g[j].y = t.y & m; g[j].z = t.z & m; g[j].w = t.w & m;
+    }
+}
+__device__ __forceinline__ void rows_to_chunks(unsigned* T, int r, int h, int lane, const uint4 (&g)[4], uint4 (&f)[4]) {
+    char* t = reinterpret_cast<char*>(T);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(t + (8 * j + (lane >> 3)) * 144 + (lane & 7) * 16) = g[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // one wave per workgroup: its LDS operations stay in order; the fence
+    __builtin_amdgcn_wave_barrier();                           // and the wave barrier pin that order for the compiler (no instruction)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const uint4*>(t + r * 144 + (2 * s + h) * 16);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 // the same chunks -> pair-interleaved tile: even lanes emit the first four d of each chunk, odd lanes the last four
 __device__ __forceinline__ void stage_pairs_from_chunks(unsigned* Xt, int r, int h, const uint4 (&f)[4]) {
     const int odd = r & 1;
@@ -1856,6 +1885,41 @@ __device__ __forceinline__ void store_ct(void* base, size_t row_off, int h, int 
         *reinterpret_cast<uint4*>(p + 16 * j) = w;
     }
 }
+// The C tiles of both halves of d (dt = 0, 1) as WHOLE-LINE stores: after store_ct()'s permlane swap lane (r, h) owns the 16-byte
+// chunks h, 2 + h, 4 + h, 6 + h of row r -- the distribution rows_to_chunks() produces for the loads.  They go through a 32 x 144-byte
+// LDS row image and leave as eight full 128-byte lines per wave-instruction (eight lanes per row) instead of 32 bytes of each of 32
+// lines.  T must be free (4608 bytes): every earlier read of it complete (one wave per workgroup: LDS operations stay in order).
+__device__ __forceinline__ void store_rows_coalesced(unsigned* T, void* base, size_t row0_off, int ld, int S, int r, int h, int lane,
+                                                     const f32x16& c0, const f32x16& c1) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    char* t = reinterpret_cast<char*>(T);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const f32x16& c = dt ? c1 : c0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned xa = pack_bf16(c[8 * j], c[8 * j + 1]), xb = pack_bf16(c[8 * j + 2], c[8 * j + 3]);
+            const unsigned ya = pack_bf16(c[8 * j + 4], c[8 * j + 5]), yb = pack_bf16(c[8 * j + 6], c[8 * j + 7]);
+            const u32x2 sa = __builtin_amdgcn_permlane32_swap(xa, ya, false, false);
+            const u32x2 sb = __builtin_amdgcn_permlane32_swap(xb, yb, false, false);
+            const uint4 w = {sa.x, sb.x, sa.y, sb.y};
+            *reinterpret_cast<uint4*>(t + r * 144 + (2 * (2 * dt + j) + h) * 16) = w;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned short* p = reinterpret_cast<unsigned short*>(base) + row0_off + 8 * (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * j + (lane >> 3);
+        const uint4 v = *reinterpret_cast<const uint4*>(t + row * 144 + (lane & 7) * 16);
+        if (row < S) *reinterpret_cast<uint4*>(p + (size_t)row * ld) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 // bias-gradient partial of one projection: sum_rows X[row][d] * w[row] for d = 32h + r, X from its pair-interleaved tile,
 // w (f32, one per row) broadcast from LDS.  Equals the column sum over this sentence of the gradient the kernel stores.
 __device__ __forceinline__ float weighted_colsum(const unsigned* Xt, const float* w, int r, int h) {
@@ -1891,8 +1955,10 @@ __device__ unsigned long long* g_nn_diag = nullptr;
 #define NN_DIAG_STORE(t0, t1, t2)
 #endif
 
+template <bool COAL, bool STC>
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned Vt[16 * AM_LDT];
+    static_assert(16 * AM_LDT * 4 == 32 * 144, "the pair-interleaved tile doubles as the 32 x 144-byte row image of rows_to_chunks()");
     NN_T(nn_t0)
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
@@ -1900,9 +1966,16 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
     const int rk = kvalid ? r : p.Sk - 1, rq = qvalid ? r : p.Sq - 1;
     const int64_t mv = attn_mask_element(p, b);                        // the first load out: its wait leaves the row loads in flight
     uint4 kf[4], qf[4], vf[4];
-    load_row_chunks(p.k, ((size_t)b * p.Sk + rk) * p.ldk + hd * AT_D, h, kvalid, kf);
-    load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
-    load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
+    uint4 gk[COAL ? 4 : 1], gq[COAL ? 4 : 1], gv[COAL ? 4 : 1];
+    if constexpr (COAL) {
+        load_rows_coalesced(p.k, (size_t)b * p.Sk * p.ldk + hd * AT_D, p.ldk, p.Sk, lane, gk);
+        load_rows_coalesced(p.q, (size_t)b * p.Sq * p.ldq + hd * AT_D, p.ldq, p.Sq, lane, gq);
+        load_rows_coalesced(p.v, (size_t)b * p.Sk * p.ldv + hd * AT_D, p.ldv, p.Sk, lane, gv);
+    } else {
+        load_row_chunks(p.k, ((size_t)b * p.Sk + rk) * p.ldk + hd * AT_D, h, kvalid, kf);
+        load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
+        load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
+    }
     // the dropout bits need nothing that is being loaded: ~2300 cycles of Philox per wave (quarter-rate 32 x 32 multiplies) drawn
     // while the rows travel -- every wave of the launch is in the same phase, so nothing else would use the VALU then
     const unsigned long long seed = attn_seed(p);
@@ -1913,6 +1986,11 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
         for (int v = 0; v < 16; ++v) keep[v] = 1.0f;
     }
     const unsigned long long kmask = attn_mask_ballot(p, mv);
+    if constexpr (COAL) {
+        rows_to_chunks(Vt, r, h, lane, gk, kf);
+        rows_to_chunks(Vt, r, h, lane, gq, qf);
+        rows_to_chunks(Vt, r, h, lane, gv, vf);
+    }
     f32x16 acc = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma32(kf[s], qf[s], acc);      // S^T[key][query]
@@ -1929,23 +2007,29 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
     acc_to_frags(s, pf);
     __syncthreads();
     NN_T(nn_t2)                                                       // (softmax and dropout done: only P.V and the stores are left)
+    f32x16 o2[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
-        f32x16 o = zero16();
+        o2[dt] = zero16();
 #pragma unroll
-        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<1>(Vt, 32 * dt + r, h, st), pf[st], o);   // O^T[d][query]
-        if (qvalid) store_ct(p.out, ((size_t)b * p.Sq + r) * p.ldo + hd * AT_D, h, 32 * dt, o);
+        for (int st = 0; st < 2; ++st) o2[dt] = mfma32(frag_from_pairs<1>(Vt, 32 * dt + r, h, st), pf[st], o2[dt]);   // O^T[d][query]
+        if (!STC && qvalid) store_ct(p.out, ((size_t)b * p.Sq + r) * p.ldo + hd * AT_D, h, 32 * dt, o2[dt]);
     }
+    if constexpr (STC) store_rows_coalesced(Vt, p.out, (size_t)b * p.Sq * p.ldo + hd * AT_D, p.ldo, p.Sq, r, h, lane, o2[0], o2[1]);
     if (qvalid && h == 0 && p.lse) p.lse[((size_t)b * p.nh + hd) * p.Sq + r] = lse;
     NN_DIAG_STORE(nn_t0, nn_t1, nn_t2)
 }
 
+template <bool COAL, bool STC>
 __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     // ONE pair-interleaved staging tile, used for K, then Q, then dO (their row chunks stay in registers): 10 KiB of LDS per
     // (sentence, head) instead of 19 KiB, so that all B * nh waves of a step-sized launch (3072 at bert-base, 12 per CU) are
     // resident at once -- with three tiles the LDS admitted 8 per CU and the launch ran one and a half rounds of a latency-bound kernel
     __shared__ __attribute__((aligned(16))) unsigned Xt[16 * AM_LDT];
-    __shared__ __attribute__((aligned(16))) unsigned TD[AT_S * AM_LDX], TP[AT_S * AM_LDX];
+    __shared__ __attribute__((aligned(16))) unsigned TDP[2 * AT_S * AM_LDX];      // dS | P~ transposed images; afterwards the row image
+    unsigned* const TD = TDP;                                                     // of the three gradients' whole-line stores
+    unsigned* const TP = TDP + AT_S * AM_LDX;
+    static_assert(2 * AT_S * AM_LDX * 4 >= 32 * 144, "the transposed images double as the row image of store_rows_coalesced()");
     __shared__ __attribute__((aligned(16))) float Wv[3 * AT_S];
     NN_T(nn_t0)
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
@@ -1954,10 +2038,18 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     const int rk = kvalid ? r : p.Sk - 1, rq = qvalid ? r : p.Sq - 1;
     const int64_t mv = attn_mask_element(p, b);                        // (see attn_fwd_mfma_kernel)
     uint4 kf[4], qf[4], vf[4], gf[4];
-    load_row_chunks(p.k, ((size_t)b * p.Sk + rk) * p.ldk + hd * AT_D, h, kvalid, kf);
-    load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
-    load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
-    load_row_chunks(p.g_out, ((size_t)b * p.Sq + rq) * p.ldo + hd * AT_D, h, qvalid, gf);
+    uint4 gk[COAL ? 4 : 1], gq[COAL ? 4 : 1], gv[COAL ? 4 : 1], gg[COAL ? 4 : 1];
+    if constexpr (COAL) {                                              // (see load_rows_coalesced)
+        load_rows_coalesced(p.k, (size_t)b * p.Sk * p.ldk + hd * AT_D, p.ldk, p.Sk, lane, gk);
+        load_rows_coalesced(p.q, (size_t)b * p.Sq * p.ldq + hd * AT_D, p.ldq, p.Sq, lane, gq);
+        load_rows_coalesced(p.v, (size_t)b * p.Sk * p.ldv + hd * AT_D, p.ldv, p.Sk, lane, gv);
+        load_rows_coalesced(p.g_out, (size_t)b * p.Sq * p.ldo + hd * AT_D, p.ldo, p.Sq, lane, gg);
+    } else {
+        load_row_chunks(p.k, ((size_t)b * p.Sk + rk) * p.ldk + hd * AT_D, h, kvalid, kf);
+        load_row_chunks(p.q, ((size_t)b * p.Sq + rq) * p.ldq + hd * AT_D, h, qvalid, qf);
+        load_row_chunks(p.v, ((size_t)b * p.Sk + rk) * p.ldv + hd * AT_D, h, kvalid, vf);
+        load_row_chunks(p.g_out, ((size_t)b * p.Sq + rq) * p.ldo + hd * AT_D, h, qvalid, gf);
+    }
     const unsigned long long seed = attn_seed(p);
     float keep[16];
     if (p.p_drop > 0.f) attn_keep16<1>(p, bh, r, h, keep, &seed);      // drawn while the rows travel
@@ -1966,6 +2058,12 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
         for (int v = 0; v < 16; ++v) keep[v] = 1.0f;
     }
     const unsigned long long kmask = attn_mask_ballot(p, mv);
+    if constexpr (COAL) {
+        rows_to_chunks(Xt, r, h, lane, gk, kf);
+        rows_to_chunks(Xt, r, h, lane, gq, qf);
+        rows_to_chunks(Xt, r, h, lane, gv, vf);
+        rows_to_chunks(Xt, r, h, lane, gg, gf);
+    }
     f32x16 accS = zero16(), accP = zero16();
 #pragma unroll
     for (int s = 0; s < 4; ++s) accS = mfma32(kf[s], qf[s], accS);     // S^T[key][query]
@@ -1997,19 +2095,21 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     acc_to_frags(ds, dsf);
     __syncthreads();
     NN_T(nn_t2)                                                       // (P, dS ready and staged: three products and the stores are left)
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {                        // dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
-        f32x16 o = zero16();
-#pragma unroll
-        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<1>(Xt, 32 * dt + r, h, st), dsf[st], o);
-        if (qvalid) store_ct(p.g_q, ((size_t)b * p.Sq + r) * p.ldq + hd * AT_D, h, 32 * dt, o);
-    }
     uint4 tdf[2], tpf[2];                                   // lane = key r: dS[query 16st + 8h + t][r], P~[..][r]
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < 2; ++st) {                        // (read before dQ: the images are then free for the gradients' row image)
         tdf[st] = *reinterpret_cast<const uint4*>(TD + r * AM_LDX + 8 * st + 4 * h);
         tpf[st] = *reinterpret_cast<const uint4*>(TP + r * AM_LDX + 8 * st + 4 * h);
     }
+    f32x16 o2[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {                        // dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
+        o2[dt] = zero16();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) o2[dt] = mfma32(frag_from_pairs<1>(Xt, 32 * dt + r, h, st), dsf[st], o2[dt]);
+        if (!STC && qvalid) store_ct(p.g_q, ((size_t)b * p.Sq + r) * p.ldq + hd * AT_D, h, 32 * dt, o2[dt]);
+    }
+    if constexpr (STC) store_rows_coalesced(TDP, p.g_q, (size_t)b * p.Sq * p.ldq + hd * AT_D, p.ldq, p.Sq, r, h, lane, o2[0], o2[1]);
     const bool partials = p.pb_q || p.pb_k || p.pb_v;       // wave-uniform
     const size_t col = (size_t)hd * AT_D + 32 * h + r;
     if (partials) {
@@ -2036,22 +2136,24 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnParams p) {
     __syncthreads();
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {                        // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
-        f32x16 o = zero16();
+        o2[dt] = zero16();
 #pragma unroll
-        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<0>(Xt, 32 * dt + r, h, st), tdf[st], o);
-        if (kvalid) store_ct(p.g_k, ((size_t)b * p.Sk + r) * p.ldk + hd * AT_D, h, 32 * dt, o);
+        for (int st = 0; st < 2; ++st) o2[dt] = mfma32(frag_from_pairs<0>(Xt, 32 * dt + r, h, st), tdf[st], o2[dt]);
+        if (!STC && kvalid) store_ct(p.g_k, ((size_t)b * p.Sk + r) * p.ldk + hd * AT_D, h, 32 * dt, o2[dt]);
     }
+    if constexpr (STC) store_rows_coalesced(TDP, p.g_k, (size_t)b * p.Sk * p.ldk + hd * AT_D, p.ldk, p.Sk, r, h, lane, o2[0], o2[1]);
     if (partials && p.pb_k) p.pb_k[(size_t)b * p.ldp_kv + col] = weighted_colsum(Xt, Wv + 32, r, h);
     __syncthreads();                                        // ... and now dO
     stage_pairs_from_chunks(Xt, r, h, gf);
     __syncthreads();
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {                        // dV^T[d][key] = sum_q dO^T[d][q] P~[q][key]
-        f32x16 o = zero16();
+        o2[dt] = zero16();
 #pragma unroll
-        for (int st = 0; st < 2; ++st) o = mfma32(frag_from_pairs<0>(Xt, 32 * dt + r, h, st), tpf[st], o);
-        if (kvalid) store_ct(p.g_v, ((size_t)b * p.Sk + r) * p.ldv + hd * AT_D, h, 32 * dt, o);
+        for (int st = 0; st < 2; ++st) o2[dt] = mfma32(frag_from_pairs<0>(Xt, 32 * dt + r, h, st), tpf[st], o2[dt]);
+        if (!STC && kvalid) store_ct(p.g_v, ((size_t)b * p.Sk + r) * p.ldv + hd * AT_D, h, 32 * dt, o2[dt]);
     }
+    if constexpr (STC) store_rows_coalesced(TDP, p.g_v, (size_t)b * p.Sk * p.ldv + hd * AT_D, p.ldv, p.Sk, r, h, lane, o2[0], o2[1]);
     if (partials && p.pb_v) p.pb_v[(size_t)b * p.ldp_kv + col] = weighted_colsum(Xt, Wv + 64, r, h);
     NN_DIAG_STORE(nn_t0, nn_t1, nn_t2)
 }
@@ -2762,6 +2864,16 @@ int kvq_dropout(const void* x, int64_t n, float p_drop, uint64_t seed, uint32_t 
 
 static thread_local int g_attn_variant = 2;   // per calling thread; bf16 io: 2 = MFMA kernels, 1 = packed-dot kernels (v_dot2c_f32_bf16), 0 = convert-and-fma kernels
 
+static bool attn_coalesced() {       // KVQ_ATTN_COAL=0: A/B switch (read once): row loads of the MFMA attention kernels as row chunks per lane
+    static const bool on = [] { const char* e = getenv("KVQ_ATTN_COAL"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+static bool attn_store_coalesced() { // KVQ_ATTN_STC=0: A/B switch: the gradients / context rows as 16-byte pieces per lane (store_ct)
+    static const bool on = [] { const char* e = getenv("KVQ_ATTN_STC"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int kvq_attn_set_variant(int variant) {
     KVQ_REQUIRE(variant >= 0 && variant <= 2, "kvq_attn_set_variant: variant %d unknown (0 fma, 1 dot2, 2 mfma)", variant);
     g_attn_variant = variant;
@@ -2797,7 +2909,12 @@ int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mas
         return check_launch("attn_fwd_blk_kernel");
     }
     if (io_dtype == KVQ_F32) hipLaunchKernelGGL(attn_fwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
-    else if (al && g_attn_variant == 2) hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
+    else if (al && g_attn_variant == 2) {
+        const dim3 grid((unsigned)(B * nh));
+        if (attn_coalesced() && attn_store_coalesced()) hipLaunchKernelGGL((attn_fwd_mfma_kernel<true, true>), grid, dim3(64), 0, st, p);
+        else if (attn_coalesced()) hipLaunchKernelGGL((attn_fwd_mfma_kernel<true, false>), grid, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((attn_fwd_mfma_kernel<false, false>), grid, dim3(64), 0, st, p);
+    }
     else if (al && g_attn_variant == 1) hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     return check_launch("attn_fwd_kernel");
@@ -2840,7 +2957,13 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const int6
         hipLaunchKernelGGL(attn_bwd_blk_dkv_kernel, dim3((unsigned)(B * nh * ((Sk + 31) / 32))), dim3(64), 0, st, p);
     } else
     if (io_dtype == KVQ_F32) hipLaunchKernelGGL(attn_bwd_kernel<KVQ_F32>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
-    else if (al && g_attn_variant == 2) { hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p); emits_partials = true; }
+    else if (al && g_attn_variant == 2) {
+        const dim3 grid((unsigned)(B * nh));
+        if (attn_coalesced() && attn_store_coalesced()) hipLaunchKernelGGL((attn_bwd_mfma_kernel<true, true>), grid, dim3(64), 0, st, p);
+        else if (attn_coalesced()) hipLaunchKernelGGL((attn_bwd_mfma_kernel<true, false>), grid, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((attn_bwd_mfma_kernel<false, false>), grid, dim3(64), 0, st, p);
+        emits_partials = true;
+    }
     else if (al && g_attn_variant == 1) hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_kernel<KVQ_BF16>, dim3((unsigned)(B * nh)), dim3(64), 0, st, p);
     rc = check_launch("attn_bwd_kernel");

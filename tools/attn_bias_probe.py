@@ -43,7 +43,12 @@ def timed(fn):
     return e0.elapsed_time(e1) / NSET * 1e3
 
 
-cases = {"attn_bwd, no partials": lambda i: bwd(i, False), "attn_bwd + q/k/v bias partials": lambda i: bwd(i, True),
+def fwd(i, causal=False):
+    t = qkv[i]
+    nnops.attn_fwd(t[:, :H], t[:, H:2 * H], t[:, 2 * H:], mask, B, nh, S, S, causal, 0.1, 9, 3, out=go[(i + 1) % NSET])
+
+
+cases = {"attn_fwd": lambda i: fwd(i), "attn_bwd, no partials": lambda i: bwd(i, False), "attn_bwd + q/k/v bias partials": lambda i: bwd(i, True),
          "attn_bwd causal + partials": lambda i: bwd(i, True, True),
          "colsum_partial of [N, 3H]": lambda i: nnops.colsum_partial(gq[i]),
          "device copy 50 MB (yardstick)": lambda i: gq[i].copy_(qkv[i])}
