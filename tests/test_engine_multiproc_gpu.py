@@ -387,3 +387,71 @@ def test_two_ranks_bf16_optimizer_moves_and_the_ranks_stay_bit_identical(tmp_pat
             assert not bad, f"{tag} step {step}: ranks differ in {bad}"
         losses = [rep[(tag, s, "loss")] for s in range(1, MOVE_STEPS + 1)]
         assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# The plain Bagon step (decoder ids != encoder ids) over two ranks: the gradient exchange is the same code, but both word-embedding
+# tables now take gradients summed over DIFFERENT id sets per rank, and there is no codebook gradient behind the buffer's head.
+# ----------------------------------------------------------------------------------------------------------------------------
+def _build_bagon():
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    from models.bagon.Bagon import Bagon
+    torch.manual_seed(0)
+    return Bagon("kvq-bert-tiny-nodrop", "kvq-bert-tiny-nodrop", True, compute_dtype=torch.float32).cuda().train()
+
+
+def _data_bagon():
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(1000, 2000, (8, 12), generator=g)
+    lens = torch.randint(3, 13, (8,), generator=g)
+    ids = ids * (torch.arange(12)[None] < lens[:, None])
+    noise = torch.randint(1000, 2000, (8, 12), generator=g)
+    dec = torch.where(torch.rand((8, 12), generator=g) < 0.3, noise, ids) * (ids != 0)
+    return ids.cuda(), (ids != 0).long().cuda(), dec.cuda(), (ids != 0).long().cuda()
+
+
+def _worker_bagon(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    import torch.distributed as dist
+    from kvq import ddp
+    from kvq.engine import TrainEngine
+    torch.cuda.set_device(0)
+    ddp.init_distributed("gloo")
+    e, em, d, dm = _data_bagon()
+    half = slice(rank * 4, rank * 4 + 4)
+    saved = {}
+    for tag, use_graph in (("eager", False), ("graph", True)):
+        model = _build_bagon()
+        ddp.broadcast_parameters(model)
+        eng = TrainEngine(model, lr=1e-3, bucket_mib=0)
+        eng.use_graph = use_graph
+        assert eng.world == 2 and not eng.has_vq
+        for _ in range(STEPS):
+            eng.train_step(e[half], em[half], dec_ids=d[half], dec_mask=dm[half])
+        torch.cuda.synchronize()
+        if use_graph:
+            assert len(eng._graphs) == 1
+        saved[tag] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    if rank == 0:
+        torch.save(saved, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_bagon_step_equal_single_process(tmp_path):
+    out = str(tmp_path / "dp_bagon.pt")
+    mp.spawn(_worker_bagon, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    bad = _differences(got["graph"], got["eager"], STEPS)
+    assert not bad, ("graph vs eager", bad[:5])
+    sys.path.insert(0, os.path.join(ROOT, "kindergarten-vq-vae_amd"))
+    from kvq.engine import TrainEngine
+    model = _build_bagon()
+    eng = TrainEngine(model, lr=1e-3)
+    eng.use_graph = False
+    e, em, d, dm = _data_bagon()
+    for _ in range(STEPS):                        # equal token counts per half: the mean of the rank means is the global mean
+        eng.train_step(e, em, dec_ids=d, dec_mask=dm)
+    bad = _differences(got["eager"], model.state_dict(), STEPS)
+    assert not bad, ("two ranks vs one process", bad[:5])
