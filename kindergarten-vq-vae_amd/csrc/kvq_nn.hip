@@ -1791,8 +1791,8 @@ __device__ __forceinline__ void load_row_chunks(const void* base, size_t row_off
 }
 // The same row chunks, fetched in WHOLE cache lines: wave-instruction j reads rows 8j .. 8j + 7 of the (sentence, head) operand,
 // eight lanes per row, 16 bytes per lane -- eight full 128-byte lines per instruction.  load_row_chunks() asks for 32 bytes of each
-// of 32 lines per instruction and comes back to every line four times; with 12 waves x 4 operands x 4 KiB in flight per CU those
-// lines do not survive in the 32-KiB vector cache, so most of them travel from L2 more than once.  rows_to_chunks() then moves
+// of 32 lines per instruction and comes back to every line four times: the same bytes from L2 (counted: profiles/r04_attn_bwd.md), but
+// 3.8 x the vector-cache accesses -- 29.9 -> 28.6 us for the backward kernel, and with the stores below 24.7.  rows_to_chunks() then moves
 // the data to the lanes the MFMA operands want it on (lane (r, h): chunks h, 2 + h, 4 + h, 6 + h of row r) through a 32 x 144-byte
 // LDS image -- the 4608 bytes of the kernel's pair-interleaved tile, before that tile is used for anything else.
 __device__ __forceinline__ void load_rows_coalesced(const void* base, size_t row0_off, int ld, int S, int lane, uint4 (&g)[4]) {
