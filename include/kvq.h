@@ -11,7 +11,9 @@
  *   - every function returns 0 on success, a negative KVQ_E_* code on failure; the message of the last
  *     failure on the calling thread is kvq_last_error().  Nothing throws, nothing is allocated or freed
  *     on behalf of the caller, no host synchronisation happens: all work is enqueued on `stream`
- *     (a hipStream_t passed as void*; NULL = the null stream).  All entry points are hipGraph-capturable.
+ *     (a hipStream_t passed as void*; NULL = the null stream).  All entry points are hipGraph-capturable and enqueue
+ *     KERNELS only: no stream memset, no memcpy (a memset captured as a graph node was observed in round 4 not to keep its
+ *     stream order ahead of the next kernel node, profiles/r04_fp8.md; kvq_graph_census lets a caller check what it captured).
  *   - all pointers are DEVICE pointers unless the name ends in _host.
  *   - tensors are dense row-major; "io dtype" is the storage type of activations (z, z_q, g_zq, g_z, logits):
  *     KVQ_F32 or KVQ_BF16.  The codebook E and its gradient are always f32, all arithmetic is f32
@@ -55,6 +57,23 @@ extern "C" {
 int kvq_version(void);
 const char* kvq_last_error(void);
 
+/* What a captured hipGraph consists of (host call, no stream): counts_host[KVQ_GRAPH_NODE_KINDS] = nodes of `graph` (a hipGraph_t)
+ * by kind.  The TrainEngine's step graphs must hold kernel nodes only (tests/test_graph_nodes_gpu.py asserts it on the graphs
+ * the benchmark replays); no reference counterpart. */
+#define KVQ_GRAPH_NODE_KERNEL 0
+#define KVQ_GRAPH_NODE_MEMSET 1
+#define KVQ_GRAPH_NODE_MEMCPY 2
+#define KVQ_GRAPH_NODE_EMPTY 3  /* joins of forked streams */
+#define KVQ_GRAPH_NODE_EVENT 4  /* event record / wait nodes */
+#define KVQ_GRAPH_NODE_OTHER 5
+#define KVQ_GRAPH_NODE_KINDS 6
+int kvq_graph_census(void* graph, int64_t* counts_host);
+
+/* dst[rows_padded][row_bytes] = the first `rows` rows of src (row stride src_ld_bytes), then zero rows.  All sizes and both
+ * buffers in multiples of 16 bytes.  Used for the operands of a weight-gradient product gy^T . x (autograd of every nn.Linear,
+ * modeling_bert.py) whose token count is not a multiple of 64, the contraction depth of one MFMA k-tile: zero rows add nothing. */
+int kvq_pad_rows(const void* src, int64_t rows, int64_t row_bytes, int64_t src_ld_bytes, void* dst, int64_t rows_padded, void* stream);
+
 /* Number of compute units / name of the device the calling thread would launch on (diagnostics only). */
 int kvq_device_info(int* cu_count, char* name, size_t name_len);
 
@@ -70,10 +89,13 @@ int kvq_device_info(int* cu_count, char* name, size_t name_len);
  *   counts   [G,K]   f32        code usage histogram = sum(min_encodings,0); may be NULL
  *   ws                         scratch of kvq_vq_workspace_bytes(N,K,D,G) bytes, 256-byte aligned
  *
- * What runs per call on the fast path (D %% 32 == 0): the f32-MFMA distance / arg-min kernel (64-bit integer atomicMin per
- * token), the HBM-bound epilogue kernel (gather, straight-through, per-token loss terms, histogram) and a single-workgroup
- * kernel that turns the partials into loss / perplexity in a fixed order -- plus, in kvq_vq_forward only, the re-layout of
- * the codebook in MFMA-fragment order.  A caller that quantises with one codebook many times between its updates (a
+ * What runs per call on the fast path (D %% 32 == 0): a small kernel that resets the minima / histogram / arrival tickets, then ONE
+ * kernel for everything of :55-85 -- the f32-MFMA distance / arg-min contraction (64-bit integer atomicMin per token); the
+ * workgroup that delivers the LAST code block of a token block goes on to gather, straight-through, per-token loss terms and
+ * histogram for those tokens, and the token block that finishes last of all turns the partials into loss / perplexity in a
+ * fixed order (no float atomics: bitwise reproducible) -- plus, in kvq_vq_forward only, the re-layout of the codebook in
+ * MFMA-fragment order.  kvq_vq_set_variant(0) splits the tail off again into an epilogue and a finalize kernel (rounds 1 - 4;
+ * the A/B arm and the checker of the fused tail; per calling thread, the product path never changes it).  A caller that quantises with one codebook many times between its updates (a
  * training loop: one update per optimiser step) keeps that copy itself: kvq_vq_pack_codebook after every codebook update,
  * kvq_vq_forward_packed per step.  Other D: one generic kernel (one wave per token) + the same finalize.
  * min_encodings ([N,K] one-hot, :67-68) is not produced here: see kvq_vq_one_hot.
@@ -83,6 +105,7 @@ size_t kvq_vq_workspace_bytes(int64_t N, int K, int D, int G);
 int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G, int io_dtype, float beta,
                    void* z_q, int64_t* idx, float* loss, float* perplexity, float* counts,
                    void* ws, size_t ws_bytes, void* stream);
+int kvq_vq_set_variant(int fused);
 /* packed: kvq_vq_packed_bytes(K, D, G) bytes, 16-byte aligned, written by kvq_vq_pack_codebook from the SAME E (D %% 32 == 0). */
 size_t kvq_vq_packed_bytes(int K, int D, int G);
 int kvq_vq_pack_codebook(const float* E, int K, int D, int G, float* packed, void* stream);
@@ -115,9 +138,6 @@ int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int 
  *   kvq_prof_read(ms, max) : after the caller has synchronised the stream, writes up to `max` durations in
  *                            milliseconds (oldest first), clears the ring and returns how many were written. */
 int kvq_prof_enable(int n_pairs);
-/* hipGraph note (ROCm 7.2): kvq_vq_forward / kvq_vq_forward_packed / kvq_vq_ema_update clear small accumulators with hipMemsetAsync.
- * Launch them eagerly (the TrainEngine does: "interludes" between its graphs); a memset captured as a graph node was observed not to
- * keep its stream order ahead of the next kernel node (profiles/r04_fp8.md).  Every other entry point launches kernels only. */
 int kvq_prof_read(float* ms_host, int max);
 
 /* Clock probe (measurement aid of bench.py; no reference counterpart): every one of kvq_clock_probe_rows() single-wave workgroups

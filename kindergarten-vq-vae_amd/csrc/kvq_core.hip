@@ -49,9 +49,60 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __r
     o[0] = xcc; o[1] = t; o[2] = r; o[3] = hwid;
 }
 
+// dst[r][:] = r < rows ? src[r][:] : 0 for r < rows_padded, in 16-byte pieces (the zero-padded operand copies of a weight-gradient
+// product whose token count is not a multiple of the MFMA kernel's 64-deep k-tile)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const uint4* __restrict__ src, int64_t rows, int64_t row16, int64_t ld16,
+                                                        uint4* __restrict__ dst, int64_t rows_padded) {
+    const int64_t total = rows_padded * row16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / row16, c = i - r * row16;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (r < rows) v = src[r * ld16 + c];
+        dst[i] = v;
+    }
+}
+
 }  // namespace kvq
 
 extern "C" {
+
+int kvq_pad_rows(const void* src, int64_t rows, int64_t row_bytes, int64_t src_ld_bytes, void* dst, int64_t rows_padded, void* stream) {
+    using namespace kvq;
+    KVQ_REQUIRE(src && dst && rows >= 0 && rows_padded >= rows && row_bytes > 0, "kvq_pad_rows: bad argument");
+    KVQ_REQUIRE(row_bytes % 16 == 0 && src_ld_bytes % 16 == 0 && src_ld_bytes >= row_bytes && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
+                "kvq_pad_rows: rows, row stride and both buffers in multiples of 16 bytes");
+    const int64_t total = rows_padded * (row_bytes / 16);
+    if (total == 0) return KVQ_OK;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(src), rows,
+                       row_bytes / 16, src_ld_bytes / 16, reinterpret_cast<uint4*>(dst), rows_padded);
+    return check_launch("pad_rows_kernel");
+}
+
+int kvq_graph_census(void* graph, int64_t* counts_host) {
+    using namespace kvq;
+    KVQ_REQUIRE(graph && counts_host, "kvq_graph_census: null pointer argument");
+    size_t n = 0;
+    if (hipGraphGetNodes((hipGraph_t)graph, nullptr, &n) != hipSuccess) return fail(KVQ_E_LAUNCH, "hipGraphGetNodes (count) failed");
+    for (int i = 0; i < KVQ_GRAPH_NODE_KINDS; ++i) counts_host[i] = 0;
+    if (n == 0) return KVQ_OK;
+    hipGraphNode_t* nodes = new hipGraphNode_t[n];
+    int rc = KVQ_OK;
+    if (hipGraphGetNodes((hipGraph_t)graph, nodes, &n) != hipSuccess) rc = fail(KVQ_E_LAUNCH, "hipGraphGetNodes failed");
+    for (size_t i = 0; rc == KVQ_OK && i < n; ++i) {
+        hipGraphNodeType t;
+        if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) { rc = fail(KVQ_E_LAUNCH, "hipGraphNodeGetType failed"); break; }
+        int slot = KVQ_GRAPH_NODE_OTHER;
+        if (t == hipGraphNodeTypeKernel) slot = KVQ_GRAPH_NODE_KERNEL;
+        else if (t == hipGraphNodeTypeMemset) slot = KVQ_GRAPH_NODE_MEMSET;
+        else if (t == hipGraphNodeTypeMemcpy) slot = KVQ_GRAPH_NODE_MEMCPY;
+        else if (t == hipGraphNodeTypeEmpty) slot = KVQ_GRAPH_NODE_EMPTY;
+        else if (t == hipGraphNodeTypeEventRecord || t == hipGraphNodeTypeWaitEvent) slot = KVQ_GRAPH_NODE_EVENT;
+        ++counts_host[slot];
+    }
+    delete[] nodes;
+    return rc;
+}
 
 int kvq_clock_probe_rows(void) { return 64; }
 

@@ -859,11 +859,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (n_tail && blockIdx.x == 0 && threadIdx.x == 1) {                    // 1 .. 3 last elements (9-code Gumbel bias, ...)
         for (int64_t e = 4 * n4; e < 4 * n4 + n_tail; ++e) {
             f32x4 pv = {p[e], 0.f, 0.f, 0.f}, mv = {m[e], 0.f, 0.f, 0.f}, vv = {v[e], 0.f, 0.f, 0.f};
-            float vm4[4] = {vmax ? vmax[e] : 0.f, 0.f, 0.f, 0.f};
+            f32x4 vm4 = {vmax ? vmax[e] : 0.f, 0.f, 0.f, 0.f};                // (16-byte aligned: adam_update4 reads it as one vector)
             const f32x4 gv = {IO<DT_G>::load1(g, e) * grad_scale, 0.f, 0.f, 0.f};
-            adam_update4(pv, gv, mv, vv, vmax ? vm4 : nullptr, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+            adam_update4(pv, gv, mv, vv, vmax ? reinterpret_cast<float*>(&vm4) : nullptr, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
             p[e] = pv.x; m[e] = mv.x; v[e] = vv.x;
-            if (vmax) vmax[e] = vm4[0];
+            if (vmax) vmax[e] = vm4.x;
             if (shadow) IO<KVQ_BF16>::store1(shadow, e, pv.x);
         }
     }

@@ -38,6 +38,12 @@ struct FwdParams {
     float* dump;        // optional [N,K] distances (debug hook), G == 1
     unsigned long long* keys;  // ws [G,N]  (v2 path: packed (distance, code) minima)
     const float* epack;        // ws [G, ceil(K/32)*32, D]  codebook in MFMA-fragment order (v3 path)
+    unsigned* tickets;         // ws [G, token blocks] arrivals of a token block's code blocks, then [G] finished token blocks (fused path)
+    float* loss;               // [G]   (fused path: written by the workgroup that finishes last)
+    float* perplexity;         // [G]
+    float* counts_f;           // [G,K] or null
+    float beta;
+    int fused;                 // 1: the last code block of a token block runs the epilogue, the last token block the final sums
     int64_t N;
     int K, D;
 };
@@ -74,6 +80,118 @@ __device__ __forceinline__ void token_epilogue(const FwdParams& p, int g, int64_
         p.tok_sumsq[(size_t)g * p.N + tok] = ss;
         p.idx[(size_t)g * p.N + tok] = (int64_t)code;
         if (HIST) atomicAdd(p.counts + (size_t)g * p.K + code, 1u);   // integer histogram: order independent, exact
+    }
+}
+
+// 4 consecutive activation elements kept RAW in registers between the global load and the LDS write
+template <int DT> struct ZRaw;
+template <> struct ZRaw<KVQ_F32> {
+    typedef f32x4 T;
+    __device__ static __forceinline__ T load(const void* base, size_t off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off); }
+    __device__ static __forceinline__ f32x4 cvt(T r) { return r; }
+};
+template <> struct ZRaw<KVQ_BF16> {
+    typedef u16x4 T;
+    __device__ static __forceinline__ T load(const void* base, size_t off) { return *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(base) + off); }
+    __device__ static __forceinline__ f32x4 cvt(T r) {
+        f32x4 v = {bf16_to_f32(r.x), bf16_to_f32(r.y), bf16_to_f32(r.z), bf16_to_f32(r.w)};
+        return v;
+    }
+};
+
+// The same for U tokens of one wave at once (fused path).  The tail of the distance kernel is a latency chain, not a bandwidth
+// problem -- 128 workgroups of 4 waves each move 0.4 MB -- so every load of the U rows is issued before the first is used: with
+// CH > 0 (D = 256 CH, compile-time) 2 U CH independent 16-byte loads per lane in ONE round trip (CH = 0: a run-time loop over D
+// with 2 U loads per pass).  D % 4 == 0.  Rows of tokens past N are loaded from row 0 and never stored.  The per-token sums of
+// squares go to `ss_out` (LDS, U doubles): the workgroup adds its 64 of them in token order.
+template <int DT, int U, int CH>
+__device__ __forceinline__ void tokens_epilogue(const FwdParams& p, int g, int64_t tok0, const int* codes, double* ss_out, int lane) {
+    size_t zrow[U];
+    const float* e[U];
+    double ss[U];
+    bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        on[u] = codes[u] >= 0;                                            // wave-uniform (codes come from LDS)
+        zrow[u] = ((size_t)g * p.N + (size_t)(on[u] ? tok0 + u : 0)) * p.D;
+        e[u] = p.E + ((size_t)g * p.K + (size_t)(on[u] ? codes[u] : 0)) * p.D;
+        ss[u] = 0.0;
+    }
+    if (CH > 0) {
+        constexpr int C = CH > 0 ? CH : 1;
+        typename ZRaw<DT>::T zr[U][C];
+        f32x4 ev[U][C];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                zr[u][j] = ZRaw<DT>::load(p.z, zrow[u] + 4 * (lane + WAVE * j));
+                ev[u][j] = *reinterpret_cast<const f32x4*>(e[u] + 4 * (lane + WAVE * j));
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const f32x4 zv = ZRaw<DT>::cvt(zr[u][j]);
+                const f32x4 df = ev[u][j] - zv;        // fl(e - z)
+                if (on[u]) IO<DT>::store4(p.z_q, zrow[u] + 4 * (lane + WAVE * j), zv + df);       // fl(z + fl(e - z))
+                ss[u] += (double)df.x * (double)df.x + (double)df.y * (double)df.y;
+                ss[u] += (double)df.z * (double)df.z + (double)df.w * (double)df.w;
+            }
+    } else {
+        for (int c = lane; c < (p.D >> 2); c += WAVE) {
+            f32x4 zv[U], ev[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { zv[u] = IO<DT>::load4(p.z, zrow[u] + 4 * c); ev[u] = *reinterpret_cast<const f32x4*>(e[u] + 4 * c); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f32x4 df = ev[u] - zv[u];
+                if (on[u]) IO<DT>::store4(p.z_q, zrow[u] + 4 * c, zv[u] + df);
+                ss[u] += (double)df.x * (double)df.x + (double)df.y * (double)df.y;
+                ss[u] += (double)df.z * (double)df.z + (double)df.w * (double)df.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const double t = wave_sum_f64(ss[u]);
+        if (lane == 0) {
+            ss_out[u] = on[u] ? t : 0.0;
+            if (on[u]) p.idx[(size_t)g * p.N + tok0 + u] = (int64_t)codes[u];
+        }
+    }
+}
+
+// loss and perplexity of codebook g from the per-token / per-code partials, in a fixed order, by ONE workgroup of NT threads
+//   VectorQuantizer.py:76-77 and :84-85.  AGENT: the partials were written by other workgroups of THIS launch (fused path).
+//   `ts`: n_part partial sums of squares (one per token: three-kernel path; one per 64-token block: fused path).
+template <int NT, bool AGENT>
+__device__ __forceinline__ void finalize_block(const double* __restrict__ ts, int64_t n_part, const unsigned* __restrict__ counts_u, int g,
+                                               int64_t N, int K, int D, float beta, float* loss, float* perplexity,
+                                               float* counts_f, double* sd, double* sf) {
+    const int t = threadIdx.x;
+    const unsigned* cu = counts_u + (size_t)g * K;
+    double a = 0.0;
+    for (int64_t n = t; n < n_part; n += NT) a += AGENT ? __hip_atomic_load(ts + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ts[n];
+    double ent = 0.0;                                // the f32 entropy terms of the reference, summed in f64 (oracle/vq_oracle.c: a
+    for (int k = t; k < K; k += NT) {                // sequential f32 sum over K = 8192 terms drifts by 2e-4; torch.sum does not)
+        const float cnt = (float)(AGENT ? __hip_atomic_load(cu + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cu[k]);
+        if (counts_f) counts_f[(size_t)g * K + k] = cnt;
+        const float pk = cnt / (float)N;                 // e_mean                       (:84)
+        ent += (double)(pk * logf(pk + 1e-10f));
+    }
+    sd[t] = a;
+    sf[t] = ent;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (t < s) { sd[t] += sd[t + s]; sf[t] += sf[t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float m = (float)(sd[0] / ((double)N * (double)D));
+        const float bm = beta * m;
+        loss[g] = m + bm;                                 // mean(.) + beta*mean(.)       (:76-77)
+        perplexity[g] = expf(-(float)sf[0]);              // (:85)
     }
 }
 
@@ -118,22 +236,6 @@ __global__ __launch_bounds__(256) void vq_pack_codebook_kernel(const float* __re
 }
 
 constexpr int T3_KC = 32;                                    // contraction floats per z stage
-
-// 4 consecutive activation elements kept RAW in registers between the global load and the LDS write
-template <int DT> struct ZRaw;
-template <> struct ZRaw<KVQ_F32> {
-    typedef f32x4 T;
-    __device__ static __forceinline__ T load(const void* base, size_t off) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off); }
-    __device__ static __forceinline__ f32x4 cvt(T r) { return r; }
-};
-template <> struct ZRaw<KVQ_BF16> {
-    typedef u16x4 T;
-    __device__ static __forceinline__ T load(const void* base, size_t off) { return *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(base) + off); }
-    __device__ static __forceinline__ f32x4 cvt(T r) {
-        f32x4 v = {bf16_to_f32(r.x), bf16_to_f32(r.y), bf16_to_f32(r.z), bf16_to_f32(r.w)};
-        return v;
-    }
-};
 
 // Diagnostic build only (-DKVQ_VQ_DIAG, tools/build_diag.sh; the product library has none of this): thread 0 of every workgroup
 // times its prologue, its stages and its stage barriers with s_memtime and stores [workgroup][8] u64 at its end.
@@ -370,6 +472,79 @@ __global__ __launch_bounds__(T2_THREADS, TT == 2 ? 3 : 4) void vq_dist_packed_ke
         if (b != ~0ull) atomicMin(p.keys + (size_t)g * p.N + tok0 + tid, b);
     }
     VQ_DIAG_END
+    if (!p.fused) return;                                    // (kernel argument: uniform)
+
+    // ---- fused tail (round 5; VectorQuantizer.py:65-85 in the launch that computed the distances).  A token block's minima are
+    // final when the LAST of its gridDim.y code blocks has added its own: every workgroup draws an arrival ticket behind its
+    // atomicMins (both agent-scope atomics; the minima were issued by wave 0 alone, whose vmcnt(0) wait below is their
+    // acknowledgement), and the one that draws gridDim.y - 1 runs the token block's epilogue -- gather, straight-through, squared
+    // error, histogram -- on the 64 rows of z its own XCD's L2 has just served to all the block's code blocks (workgroups
+    // x, x + gridDim.x, ... land on one XCD whenever gridDim.x is a multiple of 8; a placement bonus, never relied on).  The token
+    // block that finishes last of all then reduces the per-token / per-code partials to loss and perplexity in a fixed order.
+    // Nothing waits on another workgroup: a workgroup that is not last leaves.
+    __shared__ int s_codes[64];
+    __shared__ int s_last;
+    if (w == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const unsigned t = __hip_atomic_fetch_add(p.tickets + (size_t)g * gridDim.x + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = t == gridDim.y - 1;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < 64) {
+        int code = -1;
+        if (tid < TMW && tok0 + tid < p.N)
+            code = (int)(unsigned)(__hip_atomic_load(p.keys + (size_t)g * p.N + tok0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffffull);
+        s_codes[tid] = code;
+    }
+    __syncthreads();
+    if (tid < TMW && s_codes[tid] >= 0) {                    // one histogram atomic per distinct code of the token block
+        const int c = s_codes[tid];
+        unsigned cnt = 0;
+        bool first = true;
+        for (int j = 0; j < TMW; ++j) {
+            const bool same = s_codes[j] == c;
+            cnt += same ? 1u : 0u;
+            first = first && !(same && j < tid);
+        }
+        if (first) atomicAdd(p.counts + (size_t)g * p.K + c, cnt);
+    }
+    constexpr int U = 4;
+    constexpr int CH = (NST > 0 && (NST * T3_KC) % (4 * WAVE) == 0) ? NST * T3_KC / (4 * WAVE) : 0;        // D = 768: 3 chunks per lane
+    __shared__ double s_ss[64];
+    for (int t = w * U; t < TMW; t += T2_WAVES * U) tokens_epilogue<DT, U, CH>(p, g, tok0 + t, s_codes + t, s_ss + t, lane);
+    __syncthreads();
+    // the token block's sum of squares in token order, as ONE agent-scope (sc1, write-through) 8-byte store: what the workgroup
+    // that finishes LAST reads back with agent-scope loads (MI355X_MICROARCH.md, inter-workgroup visibility: "8-B agent atomics
+    // both sides"); the histogram adds above are agent-scope atomics as well
+    if (tid == 0) {
+        double a = 0.0;
+        for (int j = 0; j < TMW; ++j) a += s_ss[j];
+        __hip_atomic_store(p.tok_sumsq + (size_t)g * gridDim.x + blockIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every wave: its histogram adds (wave 0: the partial sum too) are performed
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.tickets + (size_t)gridDim.z * gridDim.x + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    double* sd = reinterpret_cast<double*>(smem);             // 2 x 256 doubles of the (dead) z stage buffers
+    finalize_block<T2_THREADS, true>(p.tok_sumsq + (size_t)g * gridDim.x, gridDim.x, p.counts, g, p.N, p.K, p.D, p.beta, p.loss, p.perplexity,
+                                     p.counts_f, sd, sd + T2_THREADS);
+}
+
+// keys := all ones, histogram := 0, arrival tickets := 0 -- ONE launch in front of the distance kernel (stream memsets are graph
+// nodes of another kind; every entry point of this library launches kernels only, see include/kvq.h)
+__global__ __launch_bounds__(256) void vq_init_kernel(unsigned long long* keys, int64_t n_keys, unsigned* counts, int64_t n_counts,
+                                                       unsigned* tickets, int64_t n_tickets) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, step = (int64_t)gridDim.x * 256;
+    for (int64_t i = i0; i < n_keys; i += step) keys[i] = ~0ull;
+    for (int64_t i = i0; i < n_counts; i += step) counts[i] = 0u;
+    for (int64_t i = i0; i < n_tickets; i += step) tickets[i] = 0u;
 }
 
 // epilogue of the v2 path: 64 tokens per workgroup, one wave per token at a time
@@ -486,32 +661,8 @@ __global__ __launch_bounds__(FIN_THREADS) void vq_finalize_kernel(const double* 
                                                                    int64_t N, int K, int D, float beta,
                                                                    float* loss, float* perplexity, float* counts_f) {
     __shared__ double sd[FIN_THREADS];
-    __shared__ double sf[FIN_THREADS];        // the f32 entropy terms of the reference, summed in f64 (oracle/vq_oracle.c: a
-    const int g = blockIdx.x, t = threadIdx.x; // sequential f32 sum over K = 8192 terms drifts by 2e-4; torch.sum does not)
-    const double* ts = tok_sumsq + (size_t)g * N;
-    const unsigned* cu = counts_u + (size_t)g * K;
-    double a = 0.0;
-    for (int64_t n = t; n < N; n += FIN_THREADS) a += ts[n];
-    double ent = 0.0;
-    for (int k = t; k < K; k += FIN_THREADS) {
-        const float cnt = (float)cu[k];
-        if (counts_f) counts_f[(size_t)g * K + k] = cnt;
-        const float pk = cnt / (float)N;                 // e_mean                       (:84)
-        ent += (double)(pk * logf(pk + 1e-10f));
-    }
-    sd[t] = a;
-    sf[t] = ent;
-    __syncthreads();
-    for (int s = FIN_THREADS / 2; s > 0; s >>= 1) {
-        if (t < s) { sd[t] += sd[t + s]; sf[t] += sf[t + s]; }
-        __syncthreads();
-    }
-    if (t == 0) {
-        const float m = (float)(sd[0] / ((double)N * (double)D));
-        const float bm = beta * m;
-        loss[g] = m + bm;                                 // mean(.) + beta*mean(.)       (:76-77)
-        perplexity[g] = expf(-(float)sf[0]);              // (:85)
-    }
+    __shared__ double sf[FIN_THREADS];
+    finalize_block<FIN_THREADS, false>(tok_sumsq + (size_t)blockIdx.x * N, N, counts_u, blockIdx.x, N, K, D, beta, loss, perplexity, counts_f, sd, sf);
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -775,8 +926,9 @@ static int pick_T(int64_t N, int K, int D) {
 static int64_t chunk_of(int64_t N, int T) { return ((N + T - 1) / T + 255) / 256 * 256; }
 
 struct WsLayout {
-    size_t counts, sumsq, e2, keys, epack, slab, slab_cnt, total;
+    size_t counts, sumsq, e2, keys, tickets, epack, slab, slab_cnt, total;
 };
+static int64_t n_tickets(int64_t N, int G) { return (int64_t)G * ((N + 63) / 64) + G; }
 static WsLayout ws_layout(int64_t N, int K, int D, int G) {
     WsLayout l;
     size_t off = 0;
@@ -785,6 +937,7 @@ static WsLayout ws_layout(int64_t N, int K, int D, int G) {
     l.sumsq = off;  off = align_up(off + (size_t)G * N * sizeof(double), 256);
     l.e2 = off;     off = align_up(off + (size_t)G * K * sizeof(float) + 16, 256);
     l.keys = off;   off = align_up(off + (size_t)G * N * sizeof(unsigned long long), 256);
+    l.tickets = off; off = align_up(off + (size_t)n_tickets(N, G) * sizeof(unsigned), 256);
     l.epack = off;  off = align_up(off + (size_t)G * ((K + 31) / 32) * 32 * D * sizeof(float), 256);
     l.slab_cnt = off; off = align_up(off + (size_t)G * T * K * sizeof(int), 256);
     l.slab = off;   off = align_up(off + (size_t)G * T * K * D * sizeof(float), 256);
@@ -802,11 +955,25 @@ static void launch_pack(const float* E, int K, int D, int G, float* epack, hipSt
 
 // distances + arg-min + epilogue (everything of the forward except the final scalar reduction); `packed`: p.epack already
 // holds the fragment-ordered codebook (kvq_vq_pack_codebook)
+// 1 (default): the distance kernel's last-arriving workgroups also run the epilogue and the final sums (one launch behind the
+// init kernel); 0: distance kernel + vq_epilogue_kernel + vq_finalize_kernel (rounds 1 - 4; kept as the A/B arm and the checker
+// of the fused tail -- kvq_vq_set_variant).  Per calling thread, like kvq_attn_set_variant.
+static thread_local int g_vq_fused = 1;
+
+static void launch_init(const FwdParams& p, int G, bool use_mfma, hipStream_t st) {
+    const int64_t nk = use_mfma ? (int64_t)G * p.N : 0, nc = (int64_t)G * p.K, nt = use_mfma ? n_tickets(p.N, G) : 0;
+    const int64_t most = nk > nc ? nk : nc;
+    const unsigned blocks = (unsigned)((most + 255) / 256 > 1024 ? 1024 : (most + 255) / 256);
+    hipLaunchKernelGGL(vq_init_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, p.keys, nk, p.counts, nc, p.tickets, nt);
+}
+
+// everything of the forward; `packed`: p.epack already holds the fragment-ordered codebook (kvq_vq_pack_codebook)
 template <int DT>
 static int launch_forward(FwdParams p, int G, bool use_mfma, bool packed, hipStream_t st) {
+    launch_init(p, G, use_mfma, st);
+    int rc = check_launch("vq_init_kernel");
+    if (rc) return rc;
     if (use_mfma) {
-        hipError_t e = hipMemsetAsync(p.keys, 0xff, (size_t)G * p.N * sizeof(unsigned long long), st);
-        if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipMemsetAsync(keys): %s", hipGetErrorString(e));
         if (!packed) launch_pack(p.E, p.K, p.D, G, const_cast<float*>(p.epack), st);
         const bool prof = prof_begin(st);
         dim3 grid((unsigned)((p.N + 63) / 64), (unsigned)((p.K + T2_CN - 1) / T2_CN), (unsigned)G);
@@ -814,20 +981,25 @@ static int launch_forward(FwdParams p, int G, bool use_mfma, bool packed, hipStr
         if (p.D == 768) hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 24>), grid, dim3(T2_THREADS), lds, st, p);
         else hipLaunchKernelGGL((vq_dist_packed_kernel<DT, true, 2, 0>), grid, dim3(T2_THREADS), lds, st, p);
         if (prof) prof_end(st);
-        int rc = check_launch("vq_dist_packed_kernel");
-        if (rc) return rc;
+        rc = check_launch("vq_dist_packed_kernel");
+        if (rc || p.fused) return rc;
         dim3 egrid((unsigned)((p.N + EP_TOK - 1) / EP_TOK), (unsigned)G);
         hipLaunchKernelGGL(vq_epilogue_kernel<DT>, egrid, dim3(EP_THREADS), 0, st, p);
-        return check_launch("vq_epilogue_kernel");
+        rc = check_launch("vq_epilogue_kernel");
+    } else {
+        const int64_t rows = (int64_t)G * p.K;
+        hipLaunchKernelGGL(row_sq_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p.E, rows, p.D,
+                           const_cast<float*>(p.e2));
+        const size_t lds = (size_t)GEN_WAVES * ((p.D + 7) & ~7) * sizeof(float);
+        if (lds > 64 * 1024) return fail(KVQ_E_INVALID, "generic path: D=%d too large (needs D %% 32 == 0 above 4096)", p.D);
+        dim3 grid((unsigned)((p.N + GEN_WAVES - 1) / GEN_WAVES), (unsigned)G);
+        hipLaunchKernelGGL(vq_fwd_generic_kernel<DT>, grid, dim3(GEN_WAVES * WAVE), lds, st, p);
+        rc = check_launch("vq_fwd_generic_kernel");
     }
-    const int64_t rows = (int64_t)G * p.K;
-    hipLaunchKernelGGL(row_sq_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p.E, rows, p.D,
-                       const_cast<float*>(p.e2));
-    const size_t lds = (size_t)GEN_WAVES * ((p.D + 7) & ~7) * sizeof(float);
-    if (lds > 64 * 1024) return fail(KVQ_E_INVALID, "generic path: D=%d too large (needs D %% 32 == 0 above 4096)", p.D);
-    dim3 grid((unsigned)((p.N + GEN_WAVES - 1) / GEN_WAVES), (unsigned)G);
-    hipLaunchKernelGGL(vq_fwd_generic_kernel<DT>, grid, dim3(GEN_WAVES * WAVE), lds, st, p);
-    return check_launch("vq_fwd_generic_kernel");
+    if (rc || !p.loss) return rc;                                // (the distance dump of the debug hook stops here)
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)G), dim3(FIN_THREADS), 0, st, p.tok_sumsq, p.counts, p.N, p.K, p.D,
+                       p.beta, p.loss, p.perplexity, p.counts_f);
+    return check_launch("vq_finalize_kernel");
 }
 
 }  // namespace kvq
@@ -883,17 +1055,20 @@ static int vq_forward_impl(const void* z, const float* E, const float* packed, i
     p.counts = (unsigned*)(w + l.counts);
     p.e2 = (const float*)(w + l.e2);
     p.keys = (unsigned long long*)(w + l.keys);
+    p.tickets = (unsigned*)(w + l.tickets);
     p.epack = packed ? packed : (const float*)(w + l.epack);
     p.dump = nullptr;
+    p.loss = loss; p.perplexity = perplexity; p.counts_f = counts; p.beta = beta;
+    p.fused = fast && g_vq_fused ? 1 : 0;
     p.N = N; p.K = K; p.D = D;
-    hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)G * K * sizeof(unsigned), st);
-    if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
-    int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, G, fast, packed != nullptr, st)
-                                 : launch_forward<KVQ_BF16>(p, G, fast, packed != nullptr, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)G), dim3(FIN_THREADS), 0, st, p.tok_sumsq, p.counts, N, K, D,
-                       beta, loss, perplexity, counts);
-    return check_launch("vq_finalize_kernel");
+    return io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, G, fast, packed != nullptr, st)
+                               : launch_forward<KVQ_BF16>(p, G, fast, packed != nullptr, st);
+}
+
+int kvq_vq_set_variant(int fused) {
+    KVQ_REQUIRE(fused == 0 || fused == 1, "kvq_vq_set_variant: 0 (three kernels) or 1 (fused tail), got %d", fused);
+    g_vq_fused = fused;
+    return KVQ_OK;
 }
 
 int kvq_vq_forward(const void* z, const float* E, int64_t N, int K, int D, int G, int io_dtype, float beta,
@@ -927,9 +1102,10 @@ int kvq_vq_debug_distances(const void* z, const float* E, int64_t N, int K, int 
     p.z = z; p.E = E; p.z_q = zq; p.idx = (int64_t*)ix;
     p.tok_sumsq = (double*)(w + l.sumsq); p.counts = (unsigned*)(w + l.counts); p.e2 = (const float*)(w + l.e2);
     p.keys = (unsigned long long*)(w + l.keys);
+    p.tickets = (unsigned*)(w + l.tickets);
     p.epack = (const float*)(w + l.epack);
+    p.loss = p.perplexity = p.counts_f = nullptr; p.beta = 0.f; p.fused = 0;
     p.dump = d; p.N = N; p.K = K; p.D = D;
-    (void)hipMemsetAsync(p.counts, 0, (size_t)K * sizeof(unsigned), st);
     int rc = io_dtype == KVQ_F32 ? launch_forward<KVQ_F32>(p, 1, use_mfma != 0, false, st)
                                  : launch_forward<KVQ_BF16>(p, 1, use_mfma != 0, false, st);
     (void)hipStreamSynchronize(st);
@@ -988,7 +1164,8 @@ int kvq_vq_ema_update(const void* z, const int64_t* idx, int64_t N, int K, int D
     p.slab = (float*)(w + l.slab);
     p.N = N; p.K = K; p.D = D; p.T = pick_T(N, K, D); p.chunk = chunk_of(N, p.T); p.beta = 0.f;
     p.slab_cnt = (int*)(w + l.slab_cnt);
-    (void)hipMemsetAsync(cnt, 0, (size_t)G * K * sizeof(unsigned), st);
+    hipLaunchKernelGGL(vq_init_kernel, dim3((unsigned)(((int64_t)G * K + 255) / 256)), dim3(256), 0, st, (unsigned long long*)nullptr,
+                       (int64_t)0, cnt, (int64_t)G * K, (unsigned*)nullptr, (int64_t)0);
     hipLaunchKernelGGL(vq_ema_counts_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)G), dim3(256), 0, st, idx, N, K, cnt);
     hipLaunchKernelGGL(vq_ema_n_kernel, dim3((unsigned)G), dim3(256), 0, st, cnt, K, decay, ema_n, tot);
     dim3 grid((unsigned)K, (unsigned)p.T, (unsigned)G);

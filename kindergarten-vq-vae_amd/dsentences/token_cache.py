@@ -33,6 +33,18 @@ class TokenCache:
         self.packed_pad_id = self.pad_id
         self.labels = labels.to(self.device) if labels is not None else None       # latent class labels [M, F], handed out per batch
 
+    @classmethod
+    def from_ids(cls, input_ids: torch.Tensor, pad_id: int = 0, device=None, labels: Optional[torch.Tensor] = None):
+        """A cache over already tokenised rows [M, L] (bench.py's synthetic ids; a corpus tokenised elsewhere)."""
+        self = cls.__new__(cls)
+        self.pad_id = int(pad_id)
+        self.input_ids = input_ids.to(torch.int64).to(device if device is not None else input_ids.device)
+        self.attention_mask = (self.input_ids != self.pad_id).to(torch.int64)
+        self.device = self.input_ids.device
+        self.packed_pad_id = self.pad_id
+        self.labels = labels.to(self.device) if labels is not None else None
+        return self
+
     def __len__(self) -> int:
         return int(self.input_ids.shape[0])
 

@@ -40,6 +40,8 @@ SIGNATURES = {
     "kvq_version": (_int, []),
     "kvq_last_error": (C.c_char_p, []),
     "kvq_device_info": (_int, [C.POINTER(_int), C.c_char_p, _sz]),
+    "kvq_graph_census": (_int, [_vp, C.POINTER(_i64)]),
+    "kvq_pad_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "kvq_prof_enable": (_int, [_int]),
     "kvq_prof_read": (_int, [C.POINTER(C.c_float), _int]),
     "kvq_clock_probe_rows": (_int, []),
@@ -47,6 +49,7 @@ SIGNATURES = {
     "kvq_vq_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "kvq_vq_uses_mfma": (_int, [_i64, _int, _int]),
     "kvq_vq_forward": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "kvq_vq_set_variant": (_int, [_int]),
     "kvq_vq_packed_bytes": (_sz, [_int, _int, _int]),
     "kvq_vq_pack_codebook": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "kvq_vq_forward_packed": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -144,6 +147,8 @@ def lib():
                 raise KvqError(f"{LIB_PATH} does not export {name} (stale build?)") from e
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("KVQ_VQ_FUSED") in ("0", "1"):       # A/B runs of the quantiser forward (tools/, bench.py): main thread only
+            l.kvq_vq_set_variant(int(os.environ["KVQ_VQ_FUSED"]))
         _lib = l
     return _lib if _fam is None else _FamilyProxy(_lib)
 

@@ -175,3 +175,33 @@ def all_reduce_mean_(t: torch.Tensor, process_group=None) -> torch.Tensor:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
         t.div_(dist.get_world_size(process_group))
     return t
+
+
+def agree(flag: bool, src: int = 0, process_group=None) -> bool:
+    """Rank `src`'s view of a host-side decision, on every rank, behind a barrier (so that what the decision is about -- a
+    checkpoint rank 0 has just written -- is on disk): every rank then enters or skips the SAME collectives."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return bool(flag)
+    dist.barrier(group=process_group)
+    box = [bool(flag)]
+    dist.broadcast_object_list(box, src=src, group=process_group)
+    return bool(box[0])
+
+
+def gather_lists(items: list, dst: int = 0, process_group=None) -> list:
+    """Every rank's list of (picklable) records concatenated in rank order on rank `dst`; the other ranks get []."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return items
+    world = dist.get_world_size(process_group)
+    out = [None] * world if dist.get_rank(process_group) == dst else None
+    dist.gather_object(items, out, dst=dst, group=process_group)
+    return [r for part in out for r in part] if out is not None else []
+
+
+def same_everywhere(obj, src: int = 0, process_group=None):
+    """Rank `src`'s value of a small picklable object on every rank (the run id: each rank reads its own clock)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, group=process_group)
+    return box[0]

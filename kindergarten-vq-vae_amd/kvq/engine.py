@@ -250,8 +250,15 @@ class _StepGraphs:
         self.idx = torch.empty(N * max(eng.G, 1), dtype=torch.int64, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float32, device=dev)         # loss, accuracy | quantiser loss, perplexity: one clone per step
         self.vq_out = self.scal[2:4]
-        self.graphs, self.inter = [torch.cuda.CUDAGraph()], []
+        # keep_graph: the captured hipGraph_t stays readable behind the executable one (node_census; a few hundred nodes)
+        self.graphs, self.inter = [torch.cuda.CUDAGraph(keep_graph=True)], []
         side = torch.cuda.Stream(device=dev)
+        # no garbage collection while a capture is open (what torch.cuda.graph does as well): a collected cycle may own HIP
+        # objects -- an older engine's kept hipGraphs -- whose destruction is not permitted while this thread captures
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         torch.cuda.synchronize(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         step0 = eng._step_host
@@ -279,6 +286,8 @@ class _StepGraphs:
                         self.graphs[-1].capture_end()
                     except Exception:
                         pass
+                if gc_was_on:
+                    gc.enable()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
 
@@ -287,9 +296,22 @@ class _StepGraphs:
         self.graphs[-1].capture_end()
         fn()
         self.inter.append(fn)
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True)
         g.capture_begin(pool=self.graphs[0].pool(), capture_error_mode="thread_local")
         self.graphs.append(g)
+
+    def node_census(self):
+        """Per captured graph of the chain: {kind: nodes} (kvq_graph_census).  A step graph must consist of kernel nodes (and the
+        empty / event nodes of a stream fork) only: a memset or memcpy node is a launch of another kind whose order against the
+        neighbouring kernel nodes this stack did not keep (profiles/r04_fp8.md) -- tests/test_graph_nodes_gpu.py."""
+        import ctypes
+        kinds = ("kernel", "memset", "memcpy", "empty", "event", "other")
+        out = []
+        for g in self.graphs:
+            counts = (ctypes.c_int64 * len(kinds))()
+            check(lib().kvq_graph_census(g.raw_cuda_graph(), counts), "kvq_graph_census")
+            out.append(dict(zip(kinds, (int(c) for c in counts))))
+        return out
 
     def run(self, ids, mask, prep, dec=None):
         """prep: TrainEngine._normalise_prepared()'s dict (pack = the whole batch as one tensor, or the sorted ids of either side)."""
@@ -784,9 +806,15 @@ class TrainEngine:
     def _wgrad_on_current_stream(self, gy, x, out):
         """bf16: a launch of its own when the output alone fills half the CUs with 256 x 256 tiles (the LM head / all-layer
         cross-K/V weight gradients), else queued for the layer's grouped launch; both contract over ALL tokens per tile (no split-K).
-        Token counts that are not multiples of 64 (the MFMA kernel's k-tile) go to the any-shape kernel."""
+        A token count that is not a multiple of 64 (the MFMA kernel's k-tile: 100 sentences x 12 tokens, the last batch of an
+        epoch) is zero-padded first -- zero rows of gy / x add nothing -- so that the step stays on the MFMA kernels; only what
+        cannot be padded in 16-byte pieces goes to the any-shape kernel."""
         Ntok, M = gy.shape
         N = x.shape[1]
+        if self._own_wgrad and Ntok % 64 != 0 and Ntok > 64:
+            padded = nnops.tn_operands_k64(gy, x)
+            if padded is not None:
+                gy, x = padded
         if self._own_wgrad and nnops.gemm_mfma_ok(gy, x, out, "tn"):
             if -(-M // 256) * -(-N // 256) >= 128:
                 self._gemm(gy, x, "tn", out=out)
@@ -1531,7 +1559,7 @@ class TrainEngine:
         check(lib().kvq_gumbel_backward(logits.data_ptr(), y_soft.data_ptr(), g_y.data_ptr(), gd.data_ptr(), N, K, float(gq.temperature),
                                         float(gq.kld_scale), self.io, g_logits.data_ptr(), stream_ptr()), "kvq_gumbel_backward")
         self.g_pw.copy_(self._mm(g_logits, z, "tn").unsqueeze(-1))
-        self.g_pb.copy_(g_logits.float().sum(0))
+        torch.sum(g_logits.float(), dim=0, out=self.g_pb)     # (out=: a same-dtype copy_ would be a memcpy NODE of a captured step)
         return self._mm(g_logits, Wp, "nn")
 
     def _adam_ranges(self, lo, hi):
@@ -1754,6 +1782,9 @@ class TrainEngine:
                     ids0, mask0, dec0 = input_ids, attention_mask, dec
                 g = self._graphs[key] = _StepGraphs(self, ids0, mask0, dec0)
             except Exception as e:                       # capture is an optimisation: never let it take a run down
+                if os.environ.get("KVQ_GRAPH_STRICT", "0") == "1":      # (tests: a capture that fails is a failure)
+                    self._abandon_capture()
+                    raise
                 import sys
                 print(f"[kvq] hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
                       f"continuing with eager launches", file=sys.stderr, flush=True)

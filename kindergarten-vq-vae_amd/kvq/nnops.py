@@ -353,10 +353,68 @@ def gemm_problem(a, b, out, layout, bias=None, accumulate=False):
                        int(accumulate))
 
 
+def pad_rows(t, rows_padded):
+    """[rows_padded, cols] copy of a row-major 2-D tensor (unit column stride) with zero rows behind its own -- one kernel."""
+    rows, cols = t.shape
+    es = t.element_size()
+    out = torch.empty((rows_padded, cols), dtype=t.dtype, device=t.device)
+    check(lib().kvq_pad_rows(t.data_ptr(), rows, cols * es, t.stride(0) * es, out.data_ptr(), rows_padded, stream_ptr()), "kvq_pad_rows")
+    return out
+
+
+def _pad_ok(t):
+    return t.dim() == 2 and t.stride(1) == 1 and (t.shape[1] * t.element_size()) % 16 == 0 and (t.stride(0) * t.element_size()) % 16 == 0 \
+        and t.data_ptr() % 16 == 0
+
+
+def tn_operands_k64(a, b):
+    """The operands of a "tn" product (both [K, .], K = tokens) with K padded to the MFMA kernel's 64-deep k-tile by zero rows
+    (which add nothing to a^T . b), or None when K % 64 == 0 already / the rows cannot be copied in 16-byte pieces.  A batch of
+    100 sentences x 12 tokens (the last batch of an epoch, any odd batch size) would otherwise put every weight gradient of the
+    step -- the [30528, 768] LM head included -- on the any-shape kernel."""
+    K = a.shape[0]
+    if K % 64 == 0 or not (_pad_ok(a) and _pad_ok(b)):
+        return None
+    Kp = (K + 63) // 64 * 64
+    return pad_rows(a, Kp), pad_rows(b, Kp)
+
+
+_ANY_WARNED = set()
+GEMM_ROUTES = {"mfma": 0, "any": 0, "tn_padded": 0, "row_split": 0}      # launches of gemm() by route (tests read it)
+
+
+def _warn_any(M, N, K, layout):
+    """Once per shape: a product of more than 64 MFLOP that no MFMA route takes (the any-shape kernel is a scalar-FMA kernel)."""
+    if 2.0 * M * N * K > 64e6 and (M, N, K, layout) not in _ANY_WARNED:
+        _ANY_WARNED.add((M, N, K, layout))
+        import warnings
+        warnings.warn(f"kvq.nnops.gemm: {layout} product M={M} N={N} K={K} ({2e-6 * M * N * K:.0f} MFLOP) runs on the any-shape kernel: "
+                      f"the MFMA kernel needs K % 64 == 0, M / N / leading dimensions % 8 == 0 and 16-byte aligned operands", stacklevel=3)
+
+
+def _gemm_any(a, b, layout, bias, out, accumulate, warn=True):
+    M, N, K = _gemm_dims(a, b, layout)
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    if out.stride(1) != 1 or (bias is not None and bias.stride(0) != 1):
+        raise KvqError("kvq.nnops.gemm: output rows / bias must be contiguous")
+    if warn:
+        _warn_any(M, N, K, layout)
+    GEMM_ROUTES["any"] += 1
+    check(lib().kvq_gemm_any_bf16(a.data_ptr(), b.data_ptr(), _p(bias), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                                  _LAYOUTS[layout], int(accumulate), stream_ptr()), "kvq_gemm_any_bf16")
+    return out
+
+
 def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
     """out[M,N] (= | +=) op(a) @ op(b) (+ bias), bf16 with f32 accumulation.  layout "nt": a[M,K], b[N,K];  "nn": a[M,K], b[K,N];
     "tn": a[K,M], b[K,N].  The MFMA GEMM of csrc/kvq_gemm2.hip whenever the product meets its requirements (gemm_mfma_ok), tile
-    from pick_tile() unless given; the any-shape kernel of csrc/kvq_gemm_any.hip otherwise.  Never a vendor library."""
+    from pick_tile() unless given.  Products that miss them only through their TOKEN count still reach it: a "tn" contraction
+    over tokens is zero-padded to a multiple of 64 (tn_operands_k64), an "nt" / "nn" product over a token count that is not a
+    multiple of 8 runs its first M - M % 8 rows there and the last rows on the any-shape kernel of csrc/kvq_gemm_any.hip, which
+    also takes everything else (with a warning above 64 MFLOP).  Never a vendor library."""
     require_gpu(a, b)
     M, N, K = _gemm_dims(a, b, layout)
     if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or (out is not None and out.dtype != torch.bfloat16):
@@ -364,21 +422,25 @@ def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
     if not gemm_mfma_ok(a, b, out, layout, bias):
-        if a.stride(1) != 1:
-            a = a.contiguous()
-        if b.stride(1) != 1:
-            b = b.contiguous()
-        if out.stride(1) != 1 or (bias is not None and bias.stride(0) != 1):
-            raise KvqError("kvq.nnops.gemm: output rows / bias must be contiguous")
-        check(lib().kvq_gemm_any_bf16(a.data_ptr(), b.data_ptr(), _p(bias), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
-                                      _LAYOUTS[layout], int(accumulate), stream_ptr()), "kvq_gemm_any_bf16")
-        return out
+        if layout == "tn" and K % 64 != 0 and K > 64:
+            padded = tn_operands_k64(a, b)
+            if padded is not None and gemm_mfma_ok(padded[0], padded[1], out, layout, bias):
+                GEMM_ROUTES["tn_padded"] += 1
+                return gemm(padded[0], padded[1], layout, bias=bias, out=out, accumulate=accumulate, tile=tile)
+        if layout != "tn" and M % 8 != 0 and M > 8 and gemm_mfma_ok(a[:M - M % 8], b, out[:M - M % 8], layout, bias):
+            M8 = M - M % 8
+            GEMM_ROUTES["row_split"] += 1
+            gemm(a[:M8], b, layout, bias=bias, out=out[:M8], accumulate=accumulate, tile=tile)
+            _gemm_any(a[M8:], b, layout, bias, out[M8:], accumulate, warn=False)                 # (at most 7 rows)
+            return out
+        return _gemm_any(a, b, layout, bias, out, accumulate)
     if tile is None:
         t = pick_tile(M, N, K)
         if persistent_pays(t, M, N, K, layout, accumulate):
             t |= 0x100
     else:
         t = TILES[tile] if isinstance(tile, str) else tile
+    GEMM_ROUTES["mfma"] += 1
     check(lib().kvq_gemm_bf16(a.data_ptr(), b.data_ptr(), _p(bias), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                               _LAYOUTS[layout], t, int(accumulate), stream_ptr()), "kvq_gemm_bf16")
     return out

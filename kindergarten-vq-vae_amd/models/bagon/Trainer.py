@@ -20,6 +20,7 @@ are consumed lazily instead of `list(dl_train)`, the "val" checkpoint is decided
 TRAIN flags, Trainer.py:437), the progress display is optional (`prg=None`)."""
 from __future__ import annotations
 
+import time as _time
 from itertools import islice
 
 import numpy as np
@@ -200,10 +201,23 @@ def checkpoint(stats_best: dict, model, checkpoint_dir: str, stage: str):
         _save_ckpt(model, f"{checkpoint_dir}/bagon_ckpt_metric_acc_{stage}_best.pth", stage)
 
 
+def _batch_size(batch) -> int:
+    """Sentences in a batch, whichever form it takes: the DataLoader's dict of strings, the token cache's dict of ids, or
+    ids tokenised per side (input_ids_encoder / input_ids_decoder, which step() accepts as well)."""
+    if isinstance(batch, dict):
+        if "sentence" in batch:
+            return len(batch["sentence"])
+        for key in ("input_ids", "input_ids_encoder", "input_ids_decoder"):
+            if key in batch:
+                return int(batch[key].shape[0])
+        raise KeyError(f"batch without sentences or ids: keys {sorted(batch)}")
+    return len(batch)
+
+
 def _stage(stage, loader, n_batches, step_kw, opt, lr_sched, pcts, decode_into, epoch, grad_sync, engine, prg=None, task=None):
     run, n_els, n_steps = init_stats_run(), 0, 0
     for batch in islice(loader, n_batches):
-        n = len(batch["sentence"]) if "sentence" in batch else int(batch["input_ids"].shape[0])
+        n = _batch_size(batch)
         n_els += n
         n_steps += 1
         with (torch.enable_grad() if opt is not None else no_grad()):
@@ -242,9 +256,14 @@ def train(prg, console, device, dl_train, dl_val, n_batches_train, n_batches_val
             prg.reset(tasks[0]); prg.reset(tasks[1])
         dec = decoded_sentences if epoch % n_epochs_to_decode_after == 0 else None
         model.train()
+        t_stage = _time.perf_counter()
         run, n, s = _stage("train", dl_train, n_batches_train, step_kw, opt, lr_sched,
                            (encoder_perturb_train_pct, decoder_perturb_train_pct), dec, epoch, grad_sync, engine, prg, tasks and tasks[0])
         stats_train_run, stats_train_best = end_of_epoch_stats_update(run, stats_train_best, n, s)
+        # sentences/s of THIS rank's train stage, loop and all (end_of_epoch_stats_update has just turned the device sums into
+        # floats: the stage's kernels have finished).  An extra log entry, not one of the reference's keys.
+        wandb_run.log({"epoch": epoch, "perf/train_s": _time.perf_counter() - t_stage, "perf/train_steps": s,
+                       "perf/train_sentences_per_s": n / max(_time.perf_counter() - t_stage, 1e-9)})
         end_of_epoch_print(stats_train_run, stats_train_best, console, epoch, True, COLOR_TRAIN, STATS_EMOJI_TRAIN, False)
         wandb_run.log(create_wandb_log_dict(epoch, stats_train_run, "train"))
         if export_checkpoint and is_main:

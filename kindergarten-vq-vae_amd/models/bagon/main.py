@@ -100,7 +100,7 @@ def main():
     if is_main:
         from rich.console import Console
         console = Console()
-    run_id = datetime.now().strftime(RUN_ID_TIMESTAMP_FORMAT)
+    run_id = ddp.same_everywhere(datetime.now().strftime(RUN_ID_TIMESTAMP_FORMAT))     # one run directory for all ranks
     run_path = f"{RUNS_DIR}/{run_id}"
     run_conf = get_config()
     run_conf.update({"n_params": model.model_params_summary_dict(), "optimizer": str(opt), "run_id": run_id, "world_size": world})
@@ -124,14 +124,18 @@ def main():
           n_epochs=N_EPOCHS, encoder_perturb_train_pct=ENCODER_PERTURB_TRAIN_PCT, encoder_perturb_val_pct=ENCODER_PERTURB_VAL_PCT,
           decoder_perturb_train_pct=DECODER_PERTURB_TRAIN_PCT, decoder_perturb_val_pct=DECODER_PERTURB_VAL_PCT, wandb_run=wandb_run,
           run_path=run_path, export_checkpoint=EXPORT_CHECKPOINT, grad_sync=grad_sync, engine=engine, is_main=is_main, **common)
+    # The test stage runs on EVERY rank (each on its shard of the test split): test() ends in the stage's all-reduce of the
+    # statistics (Trainer._sum_over_ranks), a collective every rank has to enter.  Rank 0 wrote the checkpoint; agree() puts a
+    # barrier behind that write and hands every rank rank 0's answer to "is there a best checkpoint".
     best = f"{run_path}/bagon_ckpt_loss_recon_val_best.pth"
-    if EXPORT_CHECKPOINT and is_main and os.path.exists(best):
+    if ddp.agree(EXPORT_CHECKPOINT and os.path.exists(best)):
         model.load_state_dict(torch.load(best, map_location=device)["model_state_dict"])
         if engine is not None:
             engine.sync_from_model()
         test(prg=None, console=console, device=device, dl_test=dl_test, n_batches_test=int(len(dl_test) * LIM_BATCHES_TEST_PCT),
              model=model, encoder_perturb_test_pct=ENCODER_PERTURB_TEST_PCT, decoder_perturb_test_pct=DECODER_PERTURB_TEST_PCT,
              decoded_sentences=decoded, epoch=N_EPOCHS, wandb_run=wandb_run, engine=engine, **common)
+    decoded = ddp.gather_lists(decoded)            # every rank decoded its own shard: rank 0 writes them all
     if is_main:
         import pandas as pd
         try:

@@ -15,6 +15,7 @@ stores the (batch, per-sentence) tuple by mistake), the "val" checkpoint is deci
 """
 from __future__ import annotations
 
+import time as _time
 from itertools import islice
 from math import isclose
 
@@ -179,12 +180,25 @@ def checkpoint(stats_best: dict, model, checkpoint_dir: str, stage: str):
         _save_ckpt(model, f"{checkpoint_dir}/shelgon_ckpt_loss_vq_{stage}_best.pth", stage)
 
 
+def _batch_size(batch) -> int:
+    """Sentences in a batch, whichever form it takes: the DataLoader's dict of strings, the token cache's dict of ids, or
+    ids tokenised per side (input_ids_encoder / input_ids_decoder, which step() accepts as well)."""
+    if isinstance(batch, dict):
+        if "sentence" in batch:
+            return len(batch["sentence"])
+        for key in ("input_ids", "input_ids_encoder", "input_ids_decoder"):
+            if key in batch:
+                return int(batch[key].shape[0])
+        raise KeyError(f"batch without sentences or ids: keys {sorted(batch)}")
+    return len(batch)
+
+
 def _run_stage(stage, device, loader, n_batches, model, tokenizer, tokenizer_add_special_tokens, opt, lr_sched, weights,
                vocab_size, decode_into, epoch, console, max_length, grad_sync, on_batch=None, engine=None):
     stats_run = init_stats_run()
     n_els_epoch = n_steps = 0
     for batch in islice(loader, n_batches):
-        n_els_batch = len(batch["sentence"]) if "sentence" in batch else int(batch["input_ids"].shape[0])
+        n_els_batch = _batch_size(batch)
         n_els_epoch += n_els_batch
         n_steps += 1
         ctx = torch.enable_grad() if opt is not None else no_grad()
@@ -227,10 +241,15 @@ def train(prg, console, device, dl_train, dl_val, n_batches_train: int, n_batche
 
         model.train()
         tick = (lambda: (prg.advance(tasks[1], 1), prg.advance(tasks[0], 1 / (n_batches_train + n_batches_val)))) if tasks else None
+        t_stage = _time.perf_counter()
         run, n_els, n_steps = _run_stage("train", device, dl_train, n_batches_train, model, tokenizer, tokenizer_add_special_tokens,
                                          opt, lr_sched, weights, vocab_size, decode_now, epoch, console, max_length, grad_sync, tick,
                                          engine=engine)
         stats_train_run, stats_train_best = end_of_epoch_stats_update(run, stats_train_best, n_els, n_steps)
+        # sentences/s of THIS rank's train stage, loop and all (end_of_epoch_stats_update has just turned the device sums into
+        # floats: the stage's kernels have finished).  An extra log entry, not one of the reference's keys.
+        wandb_run.log({"epoch": epoch, "perf/train_s": _time.perf_counter() - t_stage, "perf/train_steps": n_steps,
+                       "perf/train_sentences_per_s": n_els / max(_time.perf_counter() - t_stage, 1e-9)})
         end_of_epoch_print(stats_train_run, stats_train_best, console, epoch, True, COLOR_TRAIN, STATS_EMOJI_TRAIN, False)
         wandb_run.log(create_wandb_log_dict(epoch, stats_train_run, "train"))
 

@@ -126,7 +126,7 @@ def main():
         prg = Progress(TextColumn("[progress.description]{task.description}"), BarColumn(), MofNCompleteColumn(),
                        TimeElapsedColumn(), TimeRemainingColumn(), TextColumn("[bold #5B4328]{task.speed} it/s"), console=console)
 
-    run_id = datetime.now().strftime(RUN_ID_TIMESTAMP_FORMAT)
+    run_id = ddp.same_everywhere(datetime.now().strftime(RUN_ID_TIMESTAMP_FORMAT))     # one run directory for all ranks
     run_path = f"{RUNS_DIR}/{run_id}"
     run_conf = get_config()
     run_conf.update({"n_params": model.model_params_summary_dict(), "optimizer": str(opt), "run_id": run_id, "world_size": world})
@@ -151,8 +151,11 @@ def main():
           n_epochs=N_EPOCHS, vocab_size=VOCAB_SIZE, wandb_run=wandb_run, run_path=run_path, export_checkpoint=EXPORT_CHECKPOINT,
           max_length=TOKENIZED_SENTENCE_MAX_LENGTH, grad_sync=grad_sync, is_main=is_main, engine=engine, **weights)
 
+    # The test stage runs on EVERY rank (each on its shard of the test split): test() ends in the stage's all-reduce of the
+    # statistics (Trainer._sum_over_ranks), a collective every rank has to enter.  Rank 0 wrote the checkpoint; agree() puts a
+    # barrier behind that write and hands every rank rank 0's answer to "is there a best checkpoint".
     best = f"{run_path}/shelgon_ckpt_loss_recon_val_best.pth"
-    if EXPORT_CHECKPOINT and is_main and os.path.exists(best):
+    if ddp.agree(EXPORT_CHECKPOINT and os.path.exists(best)):
         model.load_state_dict(torch.load(best, map_location=device)["model_state_dict"])
         if engine is not None:
             engine.sync_from_model()
@@ -161,6 +164,7 @@ def main():
              tokenizer=tokenizer, tokenizer_add_special_tokens=TOKENIZER_ADD_SPECIAL_TOKENS, decoded_sentences=decoded_sentences,
              vocab_size=VOCAB_SIZE, epoch=N_EPOCHS, wandb_run=wandb_run, max_length=TOKENIZED_SENTENCE_MAX_LENGTH, engine=engine,
              **weights)
+    decoded_sentences = ddp.gather_lists(decoded_sentences)      # every rank decoded its own shard: rank 0 writes them all
     if is_main:
         if prg is not None:
             prg.stop()

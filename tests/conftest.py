@@ -10,6 +10,11 @@ for p in (ROOT, PKG, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, p)
 
 
+# a hipGraph capture of the training step that fails is a test FAILURE here (the engine's production behaviour is to print a
+# warning and go on with eager launches: under a test that would quietly check another program than the one that is replayed)
+os.environ.setdefault("KVQ_GRAPH_STRICT", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -41,7 +41,8 @@ def _worker(rank, world, port, out):
     assert len(sync.buckets) == 5
     g = torch.Generator().manual_seed(7)
     x = torch.randn(8, 16, generator=g); y = torch.randn(8, 8, generator=g)
-    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    per = 8 // world
+    xs, ys = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
     opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.1)
     for _ in range(2):
         sync.zero_grad()
@@ -50,16 +51,23 @@ def _worker(rank, world, port, out):
         opt.step()
     t = torch.tensor([1.0 + rank])
     ddp.all_reduce_mean_(t)
-    assert t.item() == 1.5
+    assert t.item() == (world + 1) / 2
+    # the helpers of the entry points' test stage (models/*/main.py): rank 0's decision and run id everywhere, records to rank 0
+    assert ddp.agree(rank == 0) is True and ddp.agree(rank != 0) is False
+    assert ddp.same_everywhere(f"run-of-rank-{rank}") == "run-of-rank-0"
+    rows = ddp.gather_lists([{"rank": rank, "i": i} for i in range(rank + 1)])
+    assert rows == ([{"rank": r, "i": i} for r in range(world) for i in range(r + 1)] if rank == 0 else [])
     if rank == 0:
         torch.save({k: v.clone() for k, v in model.state_dict().items()}, out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gradsync_matches_single_process_big_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradsync_matches_single_process_big_batch(tmp_path, world):
+    """world 8 = the rank count of BASELINE.json configs[2] (8 x MI355X), exercised in logic on the CPU: 8 shards of one sample."""
     out = str(tmp_path / "ddp.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got = torch.load(out)
     model = _model()
     model[2].bias.requires_grad_(False)

@@ -338,3 +338,92 @@ def test_engine_bf16_at_bert_base_shapes_with_64_token_sentences():
             cos.append((n, F.cosine_similarity(g.reshape(-1), r.reshape(-1), dim=0).item()))
     worst = min(cos, key=lambda t: t[1])
     assert worst[1] > 0.97 and np.mean([c for _, c in cos]) > 0.997, (worst, np.mean([c for _, c in cos]))
+
+
+# ---- the benchmarked row count (round 5): B = 256 sentences x S = 32 tokens = 8192 rows, where the routing differs from 2048 rows ----
+def test_engine_bf16_at_the_benchmarked_row_count(monkeypatch):
+    """kvq-bert-base-2l, bf16, 256 x 32 tokens -- bench.py's batch: the QKV projections run on the PERSISTENT kernel (at 2048 rows
+    only the all-layer cross-K/V projection does), the grouped weight-gradient queue sees 8192-row contractions, the tile rule
+    picks for 8192 rows.  Against f32 autograd through HuggingFace's forward, with the tolerances of the 2048-row test above."""
+    from kvq import nnops
+    from kvq.engine import TrainEngine
+    ids, mask = _batch(B=256, S=32, seed=11)
+    assert ids.numel() == 8192
+    m32 = _build(torch.float32)
+    ref = _hf_autograd(m32, ids, mask)
+    del m32
+    torch.cuda.empty_cache()
+    model = _build(torch.bfloat16)
+    eng = TrainEngine(model, lr=1e-4)
+    persistent, tiles = [], set()
+    real_gemm, real_grouped = nnops.gemm, nnops.gemm_grouped
+    grouped_tiles = []
+
+    def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
+        M, N, K = nnops._gemm_dims(a, b, layout)
+        if tile is None and nnops.gemm_mfma_ok(a, b, out, layout, bias):
+            t = nnops.pick_tile(M, N, K)
+            tiles.add(nnops.TILE_NAMES[t])
+            if nnops.persistent_pays(t, M, N, K, layout, accumulate):
+                persistent.append((layout, M, N, K))
+        return real_gemm(a, b, layout, bias=bias, out=out, accumulate=accumulate, tile=tile)
+
+    def grouped(problems, layout, tile):
+        grouped_tiles.append((len(problems), tile))
+        return real_grouped(problems, layout, tile)
+    monkeypatch.setattr(nnops, "gemm", gemm)
+    monkeypatch.setattr(nnops, "gemm_grouped", grouped)
+    before = dict(nnops.GEMM_ROUTES)
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+    torch.cuda.synchronize()
+    routes = {k: v - before[k] for k, v in nnops.GEMM_ROUTES.items()}
+    print("8192 rows: persistent", persistent, "tiles", sorted(tiles), "grouped", grouped_tiles, "routes", routes)
+    assert routes["any"] == 0 and routes["tn_padded"] == 0 and routes["row_split"] == 0
+    assert persistent.count(("nt", 8192, 2304, 768)) == 4, persistent            # the QKV projection of every layer (2 + 2)
+    # (the all-layer cross-K/V projection is [8192, L * 1536]: persistent at the benchmark's 12 layers -- tests/test_gemm2_gpu.py
+    #  runs that shape -- while the 2 layers of this model give a CU fewer than three tiles)
+    assert nnops.persistent_pays(nnops.pick_tile(8192, 12 * 1536, 768), 8192, 12 * 1536, 768, "nt")
+    assert any(t == "256x256" for _, t in grouped_tiles)                          # two layers' weight gradients in one round of the CUs
+    np.testing.assert_allclose(out["loss_recon"].item(), ref["loss_recon"], rtol=2e-2)
+    np.testing.assert_allclose(out["loss_vq"].item(), ref["loss_vq"], rtol=5e-2)
+    agree = (out["indices"] == ref["idx"]).float().mean().item()
+    assert agree > 0.975, f"bf16 encoder output flips {100 * (1 - agree):.2f} % of the code indices"
+    cos = []
+    for n, g in _engine_grads(eng, model).items():
+        r = ref["grads"][n]
+        if r.norm() > 0 and not n.endswith("key.bias"):
+            cos.append((n, F.cosine_similarity(g.reshape(-1), r.reshape(-1), dim=0).item()))
+    worst = min(cos, key=lambda t: t[1])
+    print("bf16 engine at 8192 rows vs f32 autograd: worst gradient cosine", worst, "mean", np.mean([c for _, c in cos]), "code agreement", agree)
+    assert worst[1] > 0.97 and np.mean([c for _, c in cos]) > 0.997, (worst, np.mean([c for _, c in cos]))
+
+
+def test_engine_bf16_replay_equals_eager_at_the_benchmarked_row_count():
+    """The schedule bench.py replays -- captured at 256 x 32 tokens, dropout on, Adam moving -- against the same steps launched
+    eagerly: losses, master weights, codebook and Adam moments bit for bit after six steps; and the captured chain holds kernel
+    nodes only (no memset / memcpy node: include/kvq.h)."""
+    from kvq.engine import TrainEngine
+    ids, mask = _batch(B=256, S=32, seed=12)
+    ends = {}
+    for use_graph in (True, False):
+        model = _build(torch.bfloat16).train()
+        eng = TrainEngine(model, lr=1e-4, seed=5)
+        eng.use_graph = use_graph
+        outs = [eng.train_step(ids, mask) for _ in range(6)]
+        torch.cuda.synchronize()
+        assert bool(eng._graphs) == use_graph
+        if use_graph:
+            census = next(iter(eng._graphs.values())).node_census()
+            print("captured step at 8192 rows:", census)
+            assert all(c["memset"] == 0 and c["memcpy"] == 0 and c["other"] == 0 for c in census), census
+            assert sum(c["kernel"] for c in census) > 100
+        ends[use_graph] = ([float(o["loss_recon"]) for o in outs], [float(o["loss_vq"]) for o in outs], eng.flat.master.clone(),
+                           eng.flat.m.clone(), eng.flat.v.clone(), model.vector_quantizer.embedding.weight.detach().clone(),
+                           outs[-1]["indices"].clone(), outs[-1]["recon_ids"].clone())
+        del eng, model
+        torch.cuda.empty_cache()
+    a, b = ends[True], ends[False]
+    assert a[0] == b[0] and a[1] == b[1], (a[:2], b[:2])
+    for x, y in zip(a[2:], b[2:]):
+        assert torch.equal(x, y)
+    assert a[0][-1] < a[0][0]

@@ -167,3 +167,43 @@ def test_shelgon_main_multi_codebook_with_ema(tmp_path):
     assert not torch.allclose(sd["vector_quantizer.ema_n"], torch.ones(4, 16))          # the EMA statistics moved
     logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
     assert any("train/loss_vq" in l for l in logs)
+
+
+@pytest.mark.parametrize("script,ckpt", [("models/bagon/main.py", "bagon_ckpt_loss_recon_val_best.pth"),
+                                         ("models/shelgon3/main.py", "shelgon_ckpt_loss_recon_val_best.pth")])
+def test_main_with_two_ranks(tmp_path, script, ckpt):
+    """The advertised multi-GPU launch line of both entry points, two ranks (gloo, sharing the one GPU): train, rank 0 writes the
+    best-val checkpoint, EVERY rank reloads it and runs the test stage on its shard -- the stage's all-reduce of the statistics
+    then has a partner on every rank (only rank 0 used to enter it and the run ended in mismatched collectives) --
+    and rank 0 writes all ranks' decoded sentences."""
+    env = dict(os.environ)
+    data = str(tmp_path / "data")
+    env.update({
+        "PYTHONPATH": PKG, "KVQ_DIST_BACKEND": "gloo",
+        "KVQ_SYNTHETIC_SENTENCES": "640", "KVQ_BATCH_SIZE": "16", "KVQ_N_EPOCHS": "2", "KVQ_TOKENIZED_SENTENCE_MAX_LENGTH": "12",
+        "KVQ_ENCODER_MODEL_NAME": "'kvq-bert-tiny'", "KVQ_DECODER_MODEL_NAME": "'kvq-bert-tiny'", "KVQ_LR": "1e-3",
+        "KVQ_RUNS_DIR": repr(str(tmp_path / "runs")),
+        "KVQ_DATASET_PATH": repr(data + "/dSentences_sentences_clean.npy"), "KVQ_SENTENCES_PATH": repr(data + "/dSentences_sentences_clean.npy"),
+        "KVQ_LATENT_CLASSES_LABELS_PATH": repr(data + "/dSentences_latent_classes_labels_clean.npy"),
+        "KVQ_LATENT_CLASSES_ONE_HOT_PATH": repr(data + "/dSentences_latent_classes_one_hot_clean.npy"),
+        "KVQ_VQ_N_E": "32", "KVQ_VQ_E_DIM": "128", "KVQ_MODEL_MODE": "'full'"})
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(PKG, script)], env=env, cwd=str(tmp_path), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    runs = glob.glob(str(tmp_path / "runs" / "*"))
+    assert len(runs) == 1, runs                                      # one run directory for both ranks (the run id is rank 0's)
+    run = runs[0]
+    conf = json.load(open(run + "/run_conf.json"))
+    assert conf["world_size"] == 2 and os.path.exists(f"{run}/{ckpt}")
+    logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
+    assert any("test/loss_recon" in l for l in logs)
+    tr = [l["train/loss_recon"] for l in logs if "train/loss_recon" in l]
+    assert len(tr) == 2 and tr[1] < tr[0]
+    import pandas as pd
+    df = pd.read_feather(run + "/decoded_sentences.feather")
+    assert len(df) > 0 and (df["stage"] == "test").any()

@@ -127,3 +127,44 @@ def test_trainer_step_contract_on_the_fixture(use_engine):
     np.testing.assert_allclose(stats["metric_acc_step_per_batch"].item(), f["acc_batch"], atol=1e-7)
     np.testing.assert_allclose(stats["metric_acc_step_per_sentence"].cpu().numpy(), f["acc_sentence"], atol=1e-7)
     assert np.array_equal(recon.cpu().numpy(), f["recon_ids"])
+
+
+# ---- the PRODUCT dtype under the same fixture (round 5): see tests/test_step_golden.py for the stated bf16 bounds ----------------
+BF16_LOGIT_ATOL = 0.03
+
+
+@pytest.mark.gpu
+def test_bagon_bf16_forward_and_step_match_the_fixture(monkeypatch):
+    """Bagon.forward and TrainEngine.forward_backward(dec_ids=...) in bf16 with every torch GEMM entry point patched to raise:
+    logits within 0.03, recon ids equal wherever the fixture's top-2 logit margin exceeds that, loss rtol 2e-2, both accuracies
+    within the tokens that may flip, gradients by cosine."""
+    from _gemm_guard import forbid_vendor_gemms
+    from kvq.engine import TrainEngine
+    model, f, grads = _gpu_model(torch.bfloat16)
+    ids_e, mask_e, ids_d, mask_d = _ids(f)
+    eng = TrainEngine(model, lr=1e-3)
+    eng.sync_from_model()
+    forbid_vendor_gemms(monkeypatch)
+    with torch.no_grad():
+        logits = model(ids_e, mask_e, ids_d, mask_d)
+    assert logits.dtype == torch.bfloat16
+    err = np.abs(logits.float().cpu().numpy() - f["logits"]).max()
+    assert err <= BF16_LOGIT_ATOL, err
+    out = eng.forward_backward(ids_e, mask_e, training=False, compute_grads=True, dec_ids=ids_d, dec_mask=mask_d)
+    s = np.sort(f["logits"].reshape(-1, f["logits"].shape[-1]), axis=-1)
+    margin = s[:, -1] - s[:, -2]
+    differ = out["recon_ids"].cpu().numpy().reshape(-1) != f["recon_ids"].reshape(-1)
+    assert not (differ & (margin > BF16_LOGIT_ATOL)).any() and differ.mean() <= 0.25, (differ.sum(), margin[differ])
+    np.testing.assert_allclose(out["loss_recon"].item(), f["loss_recon"], rtol=2e-2)
+    n_tok = differ.size
+    assert abs(out["acc"].item() - float(f["acc_batch"])) <= differ.sum() / n_tok + 1e-6
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    cos = []
+    for ename, p in eng.param_of.items():
+        n = name_of[id(p)]
+        if n in grads and not n.endswith("key.bias") and np.linalg.norm(grads[n]) > 0:
+            got = eng.flat.g(ename).float().cpu().numpy()
+            got, ref = got[: grads[n].shape[0]].reshape(-1), grads[n].reshape(-1)
+            cos.append((float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30)), n))
+    print("bf16 Bagon engine vs the f32 fixture: worst gradient cosine", min(cos), "mean", np.mean([c for c, _ in cos]))
+    assert min(cos)[0] > 0.98 and np.mean([c for c, _ in cos]) > 0.995, sorted(cos)[:5]

@@ -110,3 +110,110 @@ def test_train_engine_on_gpu_matches_the_reference_fixture():
             checked += 1
     assert checked == len(grads), (checked, sorted(grads))
     np.testing.assert_allclose(eng.gE.cpu().numpy(), f["grad_codebook"], rtol=2e-3, atol=1e-7)
+
+
+# ---- the PRODUCT dtype under the same fixture (round 5) ------------------------------------------------------------------------
+# bf16 engine: every matrix product of the fixture step runs in libkvq.so (torch.mm / addmm / bmm / matmul / F.linear raise while it
+# steps).  The fixture's hidden size 128 and 72 tokens route through the 64 x 128 tile, and the weight gradients through the
+# zero-padded token contraction (72 -> 128 rows, nnops.tn_operands_k64) into the grouped MFMA launch.
+# Stated bf16 bounds against the f32 reference fixture (bf16 keeps 8 significant bits: one ulp of a logit of magnitude <= 1 is 2^-8):
+#   code indices      equal (the fixture's smallest top-2 distance gap is 0.11)
+#   logits            |difference| <= 0.03   (measured 0.012)
+#   recon ids         equal wherever the fixture's own top-2 logit margin exceeds 0.03; at most 25 % of the 72 tokens differ at all
+#                     (a random-init model: the median top-2 margin of the fixture is 0.05, its smallest 0.001)
+#   losses            rtol 2e-2 ; perplexity rtol 2e-2
+#   gradients         cosine > 0.98 per tensor against the fixture's f32 autograd gradients, mean > 0.995
+BF16_LOGIT_ATOL = 0.03
+
+
+def _margins(f):
+    s = np.sort(f["logits"].reshape(-1, f["logits"].shape[-1]), axis=-1)
+    return s[:, -1] - s[:, -2]
+
+
+@pytest.mark.gpu
+def test_shelgon_forward_bf16_matches_the_reference_fixture(monkeypatch):
+    from _gemm_guard import forbid_vendor_gemms
+    model, f, _ = _gpu_model(torch.bfloat16)
+    ids, mask = torch.from_numpy(f["ids"]).cuda(), torch.from_numpy(f["mask"]).cuda()
+    forbid_vendor_gemms(monkeypatch)
+    with torch.no_grad():
+        vq_loss, perp, idx, logits = model(ids, mask, ids.device, False)
+    assert logits.dtype == torch.bfloat16 and idx.shape == (ids.shape[0], ids.shape[1], 1)
+    assert np.array_equal(idx.reshape(-1).cpu().numpy(), f["idx"])
+    err = np.abs(logits.float().cpu().numpy() - f["logits"]).max()
+    assert err <= BF16_LOGIT_ATOL, err
+    np.testing.assert_allclose(vq_loss.item(), f["loss_vq"], rtol=2e-2)
+    np.testing.assert_allclose(perp.item(), f["perplexity"], rtol=2e-2)
+
+
+@pytest.mark.gpu
+def test_train_engine_bf16_matches_the_reference_fixture(monkeypatch):
+    """TrainEngine.forward_backward in bf16 (dropout off) against the fixture, own GEMMs only; then the same step replayed from
+    hipGraphs must give the eager step's bits."""
+    from _gemm_guard import forbid_vendor_gemms
+    from kvq import nnops
+    from kvq.engine import TrainEngine
+    model, f, grads = _gpu_model(torch.bfloat16)
+    ids, mask = torch.from_numpy(f["ids"]).cuda(), torch.from_numpy(f["mask"]).cuda()
+    eng = TrainEngine(model, lr=1e-3)
+    eng.sync_from_model()
+    calls = {"grouped": 0}
+    real_grouped = nnops.gemm_grouped
+
+    def grouped(problems, layout, tile):
+        calls["grouped"] += len(problems)
+        return real_grouped(problems, layout, tile)
+    monkeypatch.setattr(nnops, "gemm_grouped", grouped)
+    before = dict(nnops.GEMM_ROUTES)
+    forbid_vendor_gemms(monkeypatch)
+    out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
+    torch.cuda.synchronize()
+    calls.update({k: v - before[k] for k, v in nnops.GEMM_ROUTES.items()})
+    assert calls["any"] == 0 and calls["mfma"] >= 10 and calls["grouped"] >= 8, calls       # every product on the MFMA kernels
+    assert np.array_equal(out["indices"].reshape(-1).cpu().numpy(), f["idx"])
+    recon = out["recon_ids"].cpu().numpy().reshape(-1)
+    differ = recon != f["recon_ids"].reshape(-1)
+    assert not (differ & (_margins(f) > BF16_LOGIT_ATOL)).any() and differ.mean() <= 0.25, (differ.sum(), _margins(f)[differ])
+    np.testing.assert_allclose(out["loss_recon"].item(), f["loss_recon"], rtol=2e-2)
+    np.testing.assert_allclose(out["loss_vq"].item(), f["loss_vq"], rtol=2e-2)
+    np.testing.assert_allclose(out["perplexity"].item(), f["perplexity"], rtol=2e-2)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    cos = []
+    for ename, p in eng.param_of.items():
+        n = name_of[id(p)]
+        if n in grads and not n.endswith("key.bias") and np.linalg.norm(grads[n]) > 0:
+            got = eng.flat.g(ename).float().cpu().numpy()
+            got = got[: grads[n].shape[0]].reshape(-1)
+            ref = grads[n].reshape(-1)
+            cos.append((float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30)), n))
+    gE, rE = eng.gE.cpu().numpy().reshape(-1), f["grad_codebook"].reshape(-1)
+    cos.append((float(gE @ rE / (np.linalg.norm(gE) * np.linalg.norm(rE))), "codebook"))
+    print("bf16 engine vs the f32 fixture: worst gradient cosine", min(cos), "mean", np.mean([c for c, _ in cos]), "GEMM launches", calls)
+    assert min(cos)[0] > 0.98 and np.mean([c for c, _ in cos]) > 0.995, sorted(cos)[:5]
+
+
+@pytest.mark.gpu
+def test_train_engine_bf16_replay_equals_eager_on_the_fixture(monkeypatch):
+    """Optimiser steps on the fixture batch in bf16 with dropout ON: an engine that replays the step from hipGraphs and one that
+    launches eagerly (KVQ_GRAPH=0) end with bit-identical weights and losses -- no vendor GEMM in either."""
+    from _gemm_guard import forbid_vendor_gemms
+    from kvq.engine import TrainEngine
+    f = dict(np.load(GOLDEN, allow_pickle=False))
+    ids, mask = torch.from_numpy(f["ids"]).cuda(), torch.from_numpy(f["mask"]).cuda()
+    forbid_vendor_gemms(monkeypatch)
+    ends = {}
+    for use_graph in (True, False):
+        model, _, _ = _gpu_model(torch.bfloat16)
+        model.train()
+        eng = TrainEngine(model, lr=1e-3, seed=7)
+        eng.sync_from_model()
+        eng.use_graph = use_graph
+        losses = [eng.train_step(ids, mask) for _ in range(6)]
+        torch.cuda.synchronize()
+        assert bool(eng._graphs) == use_graph
+        ends[use_graph] = ([float(o["loss_recon"]) for o in losses], [float(o["loss_vq"]) for o in losses], eng.flat.master.clone(),
+                           model.vector_quantizer.embedding.weight.detach().clone())
+    assert ends[True][0] == ends[False][0] and ends[True][1] == ends[False][1], (ends[True][:2], ends[False][:2])
+    assert torch.equal(ends[True][2], ends[False][2]) and torch.equal(ends[True][3], ends[False][3])
+    assert ends[True][0][-1] < ends[True][0][0]

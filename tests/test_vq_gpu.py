@@ -386,3 +386,37 @@ def test_nine_codebooks_full_size_equals_separate_launches(kvq):
         (l1 + (zq1.float() * gq[g].float()).sum()).backward()
         assert torch.equal(zg.grad, z.grad[g]) and torch.equal(Eg.grad, E.grad[g])
     assert counts.sum().item() == G * N
+
+
+@pytest.mark.parametrize("G,N,K,D,dtype", [(1, 8192, 512, 768, torch.bfloat16), (1, 8192, 8192, 768, torch.bfloat16),
+                                           (1, 5000, 300, 128, torch.float32), (9, 1000, 512, 96, torch.bfloat16),
+                                           (1, 33, 37, 64, torch.float32), (3, 8192, 64, 768, torch.bfloat16)])
+def test_fused_tail_equals_the_three_kernel_forward(kvq, G, N, K, D, dtype):
+    """Round 5: the distance kernel's last-arriving workgroups run the epilogue and the final sums (one launch).  The three-kernel
+    forward of rounds 1 - 4 (kvq_vq_set_variant(0): distance / epilogue / finalize) is its checker: indices, z_q and the
+    histogram bit for bit, loss and perplexity to f64-summation-order rounding, on full-size, ragged (N % 64 != 0, K % 128 != 0),
+    grouped and collapsed-histogram inputs -- twice, so that a stale arrival ticket of the first call would show in the second."""
+    from kvq import _ffi
+    lib = _ffi.lib()
+    torch.manual_seed(N + K)
+    z = torch.randn(G, N, D, device="cuda").to(dtype)
+    E = torch.randn(G, K, D, device="cuda")
+    if K == 64:
+        E[:, 1:] += 50.0                                      # (nearly) every token on code 0: one histogram address takes all adds
+    runs = {}
+    try:
+        for fused in (1, 0, 1):
+            _ffi.check(lib.kvq_vq_set_variant(fused), "kvq_vq_set_variant")
+            loss, z_q, perp, idx, counts = kvq.vector_quantize(z, E, 0.25)
+            torch.cuda.synchronize()
+            got = (idx.clone(), z_q.clone(), counts.clone(), loss.clone(), perp.clone())
+            if fused in runs:                                 # the second fused call against the first: bitwise, scalars included
+                assert all(torch.equal(a, b) for a, b in zip(got, runs[fused]))
+            runs[fused] = got
+    finally:
+        _ffi.check(lib.kvq_vq_set_variant(1), "kvq_vq_set_variant")
+    (i1, q1, c1, l1, p1), (i0, q0, c0, l0, p0) = runs[1], runs[0]
+    assert torch.equal(i1, i0) and torch.equal(q1, q0) and torch.equal(c1, c0)
+    assert c1.sum().item() == G * N
+    torch.testing.assert_close(l1, l0, rtol=1e-6, atol=0)
+    torch.testing.assert_close(p1, p0, rtol=1e-6, atol=0)
