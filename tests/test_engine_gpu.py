@@ -294,6 +294,7 @@ def test_engine_step_count_setter_moves_the_device_state():
 def test_engine_survives_a_failed_graph_capture(monkeypatch):
     """Capture is an optimisation: an error inside it leaves the engine on the eager path with the same results."""
     from kvq import engine as E
+    monkeypatch.setenv("KVQ_GRAPH_STRICT", "0")           # (tests/conftest.py makes a failed capture fatal: this test is ABOUT the fallback)
     model = _build(torch.bfloat16).train()
     eng = E.TrainEngine(model, lr=1e-3, seed=5)
     ids, mask = _batch(B=8, S=16, seed=2)
