@@ -263,6 +263,13 @@ def main():
                     "method": f"{a.family_steps} eager steps after the timed region, HIP event pair around every libkvq.so entry point, "
                               "empty-pair time subtracted"}
 
+    graph_nodes = None
+    if engine is not None and engine._graphs:
+        try:
+            graph_nodes = next(iter(engine._graphs.values())).node_census()
+        except Exception as e:                                             # a reading aid: never fails the line
+            graph_nodes = f"unavailable: {e}"
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -326,6 +333,9 @@ def main():
             "clock_mhz": clock_mhz, "clock_mhz_per_xcd": clock_per_xcd, "clock_nominal_mhz": CLOCK_NOMINAL_MHZ,
             **({"families_eager_event_pairs": families} if families else {}),
             "graph": bool(engine is not None and engine._graphs),      # False = the step ran as ~800 eager launches (capture failed or off)
+            # what the replayed step consists of, per graph of the chain (hipGraphGetNodes + hipGraphNodeGetType): kernel nodes only,
+            # no memset / memcpy node (tests/test_graph_nodes_gpu.py, profiles/r05_graph_nodes.md)
+            "graph_nodes": graph_nodes,
             "rccl_ranks": rccl_ranks, "dist_backend": (dist.get_backend() if grouped else None),
             "exposed_comm_ms_per_step": exposed_ms,
             # the whole step against the dense bf16 matrix-core peak (per GPU; a reading aid: `roofline` below is the contract's object)

@@ -69,6 +69,12 @@ struct Problem {
 
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_CE = 3;
 
+// A/B switch of the one-tile-per-workgroup kernels' prologue (round 5; -DKVQ_G2_EARLY=0 builds the round-4 form)
+#ifndef KVQ_G2_EARLY
+#define KVQ_G2_EARLY 1
+#endif
+constexpr bool G2_EARLY_START = KVQ_G2_EARLY != 0;
+
 // Diagnostic build only (-DKVQ_G2_DIAG, tools/build_diag.sh -> lib/libkvq_diag.so; the product library has none of this): one
 // wave per workgroup stamps s_memtime at the phase boundaries of its tile into a buffer nothing else reads (guide, "In-kernel stamps").
 #ifdef KVQ_G2_DIAG
@@ -137,6 +143,7 @@ struct Cfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NS = NS_;
     static constexpr bool AK = AK_, BKM = BKM_;             // operand is k-major in memory
     static constexpr int WAVES = WM * WN, THREADS = 64 * WAVES;
+    static constexpr int MINW = WAVES >= 8 ? WAVES / 4 : 2;  // waves per SIMD the register budget must allow: four-wave workgroups run in pairs
     static constexpr int TM = BM / WM, TN = BN / WN;        // wave tile
     static constexpr int FA = TM / 16, FB = TN / 16;        // fragments per k-step
     static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
@@ -589,7 +596,11 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
 //      and `sg` points at k-tile NS; on exit every wave has read its last fragments (the ring is free).
 template <class C>
 __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& sg, char* smem, int nkt, int wm, int wn, int lane) {
-    if (nkt >= C::NS) wait_vm<(C::NS - 1) * C::PPW>();
+    // EARLY (rings of three slots and more): the prologue issued k-tiles 0 .. NS-2 only; the last slot's first fill is issued
+    // inside the first MFMA cluster (see gemm2_tile)
+    constexpr bool EARLY = G2_EARLY_START && C::NS >= 3;
+    constexpr int NPRO = EARLY ? C::NS - 1 : C::NS;                        // k-tiles the prologue issued
+    if (nkt >= NPRO) wait_vm<(NPRO - 1) * C::PPW>();
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     G2_STAMP(4);
@@ -611,12 +622,18 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
     // k-tile but the first and the last NS.  With these three as compile-time constants the clusters carry no branch around
     // the DMA pieces (as run-time flags each piece sat behind an s_cbranch plus the v_cndmask / v_cmp pair hipcc builds for a
     // uniform bool: a basic-block cut every four or five MFMAs)
-    auto ktile = [&](int kt, auto steady) {
+    auto ktile = [&](int kt, auto steady, auto first) {
         constexpr bool STEADY = decltype(steady)::value;
+        constexpr bool FIRST = decltype(first)::value;                     // EARLY only: k-tile 0 also issues the WHOLE fill of slot NS-1
         const char* st = smem + slot * C::STAGE;
         __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0): f0 (its reads ended half a cluster ago)
         __builtin_amdgcn_sched_barrier(0);
-        mma<C, PH, C::PPW>(acc, f0, f1, st, 1, wm, wn, lane, sg, pslot, STEADY ? true : pending);
+        if constexpr (FIRST) {
+            pending = C::NS - 1 < nkt;
+            mma<C, 0, C::PPW>(acc, f0, f1, st, 1, wm, wn, lane, sg, C::NS - 1, pending);
+        } else {
+            mma<C, PH, C::PPW>(acc, f0, f1, st, 1, wm, wn, lane, sg, pslot, STEADY ? true : pending);
+        }
         if (STEADY || pending) sg.advance();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);                                // f1 arrived: this wave is done with `slot`
@@ -647,9 +664,9 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[C::FA][C::FB], Stager<C>& 
         slot = nslot;
     };
     int kt = 0;
-    if (nkt > 0) ktile(kt++, std::false_type{});
-    for (; kt + C::NS < nkt; ++kt) ktile(kt, std::true_type{});
-    for (; kt < nkt; ++kt) ktile(kt, std::false_type{});
+    if (nkt > 0) ktile(kt++, std::false_type{}, std::integral_constant<bool, EARLY>{});
+    for (; kt + C::NS < nkt; ++kt) ktile(kt, std::true_type{}, std::false_type{});
+    for (; kt < nkt; ++kt) ktile(kt, std::false_type{}, std::false_type{});
     __builtin_amdgcn_s_barrier();      // every wave has read its last fragments: the ring is free (it becomes the epilogue tile)
 #ifdef KVQ_G2_DIAG
     G2_STAMP_VAL(12, diag_vm);
@@ -684,8 +701,12 @@ __device__ __forceinline__ void gemm2_tile(const Problem& pr, const TileId& ti, 
     Stager<C> sg;
     sg.init(pr, smem, m0, n0, w, lane);
     G2_STAMP(10);
+    // Rings of three slots: only NS - 1 k-tiles here.  The stamps put 0.5 us per 40-KB k-tile between "issued" and "issued" (the
+    // CU's address path takes a DMA piece every ~30 cycles whoever asks), and the k loop could start 0.3 us after the FIRST k-tile
+    // was issued: the last slot's fill waits for nothing in front of the loop, so it goes into the first MFMA cluster instead.
+    constexpr int NPRO = (G2_EARLY_START && C::NS >= 3) ? C::NS - 1 : C::NS;
 #pragma unroll
-    for (int s = 0; s < C::NS; ++s) {
+    for (int s = 0; s < NPRO; ++s) {
         if (s < nkt) sg.issue(s);
         if (s == 0) G2_STAMP(11);
     }
@@ -703,7 +724,7 @@ __device__ __forceinline__ void gemm2_tile(const Problem& pr, const TileId& ti, 
 
 // several problems in one grid (the grouped weight gradients): the problem of a tile is looked up in the argument struct
 template <class C, int EPI>
-__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params P) {
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm2_kernel(Params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     G2_STAMP(0);
     G2_STAMP_VAL(1, __builtin_amdgcn_s_memrealtime());
@@ -718,7 +739,7 @@ __global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_kernel(Params 
 // wave, no s_load and no wait (14 is what the hardware preloads; a by-value struct cannot be preloaded at all).  Everything else
 // (C, bias, the epilogue's pointers) is read from `rest` when used.
 template <class C, int EPI>
-__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2s_kernel(int ntiles_band, int tiles_mn, unsigned mg_per_band, unsigned mg_full,
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm2s_kernel(int ntiles_band, int tiles_mn, unsigned mg_per_band, unsigned mg_full,
                                                                           unsigned mg_rem, int K, const unsigned short* A, const unsigned short* B,
                                                                           const unsigned short* bias, int ld_ab, int mn, Problem rest) {
     const int ntiles = ntiles_band & 0xffff, band = ntiles_band >> 16;                  // (band is signed: arithmetic shift)
@@ -852,7 +873,7 @@ __device__ __forceinline__ void epilogue_regs(const Problem& pr, const char* bia
 }
 
 template <class C, int EPI>
-__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm3_kernel(Params P) {
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm3_kernel(Params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1026,7 +1047,7 @@ __device__ __forceinline__ void cluster8(f32x4 (&acc)[C::FA][C::FB], const Frags
 }
 
 template <class C>
-__global__ __launch_bounds__(C::THREADS, C::WAVES / 4) void gemm2_f8_kernel(Params P) {
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm2_f8_kernel(Params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1101,6 +1122,8 @@ template <bool AK, bool BKM> using Cfg128x192 = Cfg<128, 192, 2, 4, AK, BKM, 3>;
 template <bool AK, bool BKM> using Cfg256x256 = Cfg<256, 256, 2, 4, AK, BKM, 2>;     // 8 waves, 128 KiB
 template <bool AK, bool BKM> using Cfg128x192p = Cfg<128, 192, 4, 2, AK, BKM, 3>;    // persistent form: an even number of 16-column blocks per wave
 template <bool AK, bool BKM> using Cfg64x128 = Cfg<64, 128, 1, 4, AK, BKM, 3>;       // 4 waves, 72 KiB: two workgroups per CU, small outputs
+template <bool AK, bool BKM> using Cfg128x192h = Cfg<128, 192, 2, 2, AK, BKM, 2>;    // 4 waves, 80 KiB: TWO workgroups per CU, each one wave
+                                                                                     // per SIMD; one's start-up / epilogue under the other's k loop
 
 template <class C, int EPI = EPI_NONE>
 static int launch_cfg(const Params& P, hipStream_t st) {
@@ -1167,6 +1190,7 @@ static void tile_of(int tile, int& bm, int& bn) {
         case KVQ_GEMM_TILE_256x192: bm = 256; bn = 192; break;
         case KVQ_GEMM_TILE_256x256: bm = 256; bn = 256; break;
         case KVQ_GEMM_TILE_64x128: bm = 64; bn = 128; break;
+        case KVQ_GEMM_TILE_128x192H: bm = 128; bn = 192; break;
         default: bm = 128; bn = 192; break;
     }
 }
@@ -1181,8 +1205,8 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
     KVQ_REQUIRE(layout == KVQ_GEMM_NT || layout == KVQ_GEMM_NN || layout == KVQ_GEMM_TN, "%s: unknown layout %d", who, layout);
     const bool persistent = (tile & KVQ_GEMM_PERSISTENT) != 0;
     tile &= ~KVQ_GEMM_PERSISTENT;
-    KVQ_REQUIRE(tile >= KVQ_GEMM_TILE_128x192 && tile <= KVQ_GEMM_TILE_64x128, "%s: unknown tile %d", who, tile);
-    KVQ_REQUIRE(!(persistent && tile == KVQ_GEMM_TILE_64x128), "%s: the 64x128 tile has no persistent form", who);
+    KVQ_REQUIRE(tile >= KVQ_GEMM_TILE_128x192 && tile <= KVQ_GEMM_TILE_128x192H, "%s: unknown tile %d", who, tile);
+    KVQ_REQUIRE(!(persistent && (tile == KVQ_GEMM_TILE_64x128 || tile == KVQ_GEMM_TILE_128x192H)), "%s: the four-wave tiles have no persistent form", who);
     int bm, bn;
     g2::tile_of(tile, bm, bn);
     (void)persistent;
@@ -1255,6 +1279,7 @@ int kvq_gemm_grouped_bf16(const kvq_gemm_problem* probs, int nprob, int layout, 
         case KVQ_GEMM_TILE_256x192: return g2::launch_layout<g2::Cfg256x192>(layout, P, st);
         case KVQ_GEMM_TILE_256x256: return g2::launch_layout<g2::Cfg256x256>(layout, P, st);
         case KVQ_GEMM_TILE_64x128: return g2::launch_layout<g2::Cfg64x128>(layout, P, st);
+        case KVQ_GEMM_TILE_128x192H: return g2::launch_layout<g2::Cfg128x192h>(layout, P, st);
         default: return g2::launch_layout<g2::Cfg128x192>(layout, P, st);
     }
 }
@@ -1270,7 +1295,8 @@ int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hou
                        int ldc, int tile, void* stream) {
     KVQ_REQUIRE(Aout && ((uintptr_t)Aout & 15) == 0, "kvq_gemm_bf16_gelu: null / misaligned second output");
     const int base = tile & ~KVQ_GEMM_PERSISTENT;
-    KVQ_REQUIRE(base == KVQ_GEMM_TILE_256x192 || base == KVQ_GEMM_TILE_128x256, "kvq_gemm_bf16_gelu: tile must be 256x192 or 128x256");
+    KVQ_REQUIRE(base == KVQ_GEMM_TILE_256x192 || base == KVQ_GEMM_TILE_128x256 || tile == KVQ_GEMM_TILE_128x192H,
+                "kvq_gemm_bf16_gelu: tile must be 256x192, 128x256 (optionally persistent) or 128x192H");
     kvq_gemm_problem q;
     q.A = A; q.B = B; q.C = Hout; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.accumulate = 0;
     g2::Params P;
@@ -1281,6 +1307,7 @@ int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hou
         if (base == KVQ_GEMM_TILE_256x192) return g2::launch_persistent<g2::Cfg256x192<true, true>, g2::EPI_GELU>(P, st);
         return g2::launch_persistent<g2::Cfg128x256<true, true>, g2::EPI_GELU>(P, st);
     }
+    if (tile == KVQ_GEMM_TILE_128x192H) return g2::launch_cfg<g2::Cfg128x192h<true, true>, g2::EPI_GELU>(P, st);
     if (tile == KVQ_GEMM_TILE_256x192) return g2::launch_cfg<g2::Cfg256x192<true, true>, g2::EPI_GELU>(P, st);
     return g2::launch_cfg<g2::Cfg128x256<true, true>, g2::EPI_GELU>(P, st);
 }

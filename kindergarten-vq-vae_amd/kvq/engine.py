@@ -413,6 +413,12 @@ class TrainEngine:
         self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get("KVQ_WG_STREAM", "0") == "1" else None
         self._wg_pending = False
         self._wg_keep_step = []
+        # opt-in (KVQ_RED_STREAM=1, round 5 experiment): the batched small reductions (bias / LayerNorm partial rows -> gradient
+        # buffer: 14 launches of ~16 us per step, nothing in backward reads their results) on a side stream, joined where the
+        # weight gradients are.  profiles/r05_gemm_ceiling.md has the A/B.
+        self.red_stream = torch.cuda.Stream(device=dev) if os.environ.get("KVQ_RED_STREAM", "0") == "1" else None
+        self._red_pending = False
+        self._red_keep_step = []
         self.use_graph = os.environ.get("KVQ_GRAPH", "1") != "0"
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -698,11 +704,13 @@ class TrainEngine:
         return torch.addmm(bias, A, Bm) if bias is not None else torch.mm(A, Bm)
 
     def _epilogue_tile(self, M, N, K):
-        """Tile of the fused-activation GEMMs (they exist for 256 x 192 and 128 x 256), or None when the plain GEMM on its best
+        """Tile of the fused-activation GEMMs (they exist for 256 x 192, 128 x 256 and the two-per-CU 128 x 192), or None when the plain GEMM on its best
         tile + the separate activation kernel (one pass over [M, N]: ~3 us + 4 bytes per element at ~3 TB/s) is modelled cheaper --
         outputs too small to give half the CUs one of the large tiles."""
         if not (self._own_fwd and self._own_epi and self.dtype == torch.bfloat16):
             return None
+        if nnops.half_cu_pays(M, N, K, "nt"):
+            return "128x192h"
         t = nnops.pick_tile(M, N, K, candidates=("256x192", "128x256"))
         plain = nnops.tile_cost_us(nnops.pick_tile(M, N, K), M, N, K) + 3.0 + M * N * 4 / 3e6
         return nnops.TILE_NAMES[t] if nnops.tile_cost_us(t, M, N, K) <= plain else None
@@ -764,6 +772,10 @@ class TrainEngine:
             torch.cuda.current_stream(self.dev).wait_stream(self.wg_stream)
             self._wg_pending = False
         self._wg_keep_step = []
+        if self._red_pending:
+            torch.cuda.current_stream(self.dev).wait_stream(self.red_stream)
+            self._red_pending = False
+        self._red_keep_step = []
 
     def _flush_reductions(self, force=True):
         """Launch the queued batched reductions and (see _flush_wgrads) the queued weight gradients; True if none stay queued."""
@@ -771,7 +783,14 @@ class TrainEngine:
         if not done and self._red_pair:
             return False                       # ... and the small sums wait with them: one launch per two layers as well
         if self._red_items:
-            nnops.reduce_batch(self._red_items)
+            if self.red_stream is not None:
+                self.red_stream.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(self.red_stream):
+                    nnops.reduce_batch(self._red_items)
+                self._red_pending = True
+                self._red_keep_step += self._red_keep       # the partial rows stay alive until the join
+            else:
+                nnops.reduce_batch(self._red_items)
         self._red_items, self._red_keep = [], []
         return done
 

@@ -2,6 +2,7 @@
 the training engine (kvq/engine.py) calls forward and backward kernels explicitly.  All work goes to the current stream."""
 from __future__ import annotations
 
+import os
 import torch
 
 from ._ffi import KvqError, check, io_dtype_of, lib, require_gpu, stream_ptr
@@ -277,7 +278,7 @@ def embed_grad(g, perm, sorted_ids, gW, accumulate=False):
 
 # ---- the GEMM family of csrc/kvq_gemm2.hip ---------------------------------------------------------------------------------
 _LAYOUTS = {"nt": 0, "nn": 1, "tn": 2}
-TILES = {"128x192": 0, "128x256": 1, "256x192": 2, "256x256": 3, "64x128": 4,
+TILES = {"128x192": 0, "128x256": 1, "256x192": 2, "256x256": 3, "64x128": 4, "128x192h": 5,
          "128x192p": 0x100, "128x256p": 0x101, "256x192p": 0x102, "256x256p": 0x103}      # p: KVQ_GEMM_PERSISTENT (layout nt only)
 TILE_NAMES = {v: k for k, v in TILES.items()}
 _TILE_DIMS = {0: (128, 192), 1: (128, 256), 2: (256, 192), 3: (256, 256), 4: (64, 128)}
@@ -332,6 +333,21 @@ def persistent_pays(t, M, N, K, layout, accumulate=False, n_cu=256):
         return False
     per_cu = -(-(-(-M // bm) * -(-N // bn)) // n_cu)
     return 3 <= per_cu <= 12
+
+
+_HALF_CU = os.environ.get("KVQ_HALF_CU", "1") != "0"          # A/B switch of the rule below (tools/, same-box runs)
+
+
+def half_cu_pays(M, N, K, layout, accumulate=False, n_cu=256):
+    """The four-wave 128 x 192 tile that runs TWO workgroups per CU ("128x192h": one's start-up and epilogue under the other's
+    k loop) instead of pick_tile()'s choice: forward ("nt") products of a short contraction whose output is 2 .. 8 such tiles per
+    CU.  Measured at 8192 rows (tools/gemm2_probe_h.py, profiles/r05_gemm_ceiling.md): [8192, 2304] x 768 34.5 us against 37.0
+    (persistent 128 x 192) and 38.7 (256 x 192); [8192, 3072] x 768 39.6 against 41.6 (256 x 192); it loses on the wide outputs
+    (LM head, all-layer cross-K/V: the 256 x 256 tile stages fewer bytes per flop), on one tile per CU and on K >= 2304."""
+    if layout != "nt" or accumulate or K // 64 > 16 or M < 128 or N < 192 or not _HALF_CU:
+        return False
+    per_cu = (-(-M // 128) * -(-N // 192)) / n_cu
+    return 2.0 <= per_cu <= 8.0
 
 
 def gemm_mfma_ok(a, b, out, layout, bias=None):
@@ -436,7 +452,9 @@ def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
         return _gemm_any(a, b, layout, bias, out, accumulate)
     if tile is None:
         t = pick_tile(M, N, K)
-        if persistent_pays(t, M, N, K, layout, accumulate):
+        if half_cu_pays(M, N, K, layout, accumulate):
+            t = TILES["128x192h"]
+        elif persistent_pays(t, M, N, K, layout, accumulate):
             t |= 0x100
     else:
         t = TILES[tile] if isinstance(tile, str) else tile

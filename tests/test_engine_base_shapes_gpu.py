@@ -342,8 +342,8 @@ def test_engine_bf16_at_bert_base_shapes_with_64_token_sentences():
 
 # ---- the benchmarked row count (round 5): B = 256 sentences x S = 32 tokens = 8192 rows, where the routing differs from 2048 rows ----
 def test_engine_bf16_at_the_benchmarked_row_count(monkeypatch):
-    """kvq-bert-base-2l, bf16, 256 x 32 tokens -- bench.py's batch: the QKV projections run on the PERSISTENT kernel (at 2048 rows
-    only the all-layer cross-K/V projection does), the grouped weight-gradient queue sees 8192-row contractions, the tile rule
+    """kvq-bert-base-2l, bf16, 256 x 32 tokens -- bench.py's batch: the QKV projections run on the two-workgroups-per-CU tile (round 5;
+    the persistent kernel before), which no product of the 2048-row test reaches, the grouped weight-gradient queue sees 8192-row contractions, the tile rule
     picks for 8192 rows.  Against f32 autograd through HuggingFace's forward, with the tolerances of the 2048-row test above."""
     from kvq import nnops
     from kvq.engine import TrainEngine
@@ -355,7 +355,7 @@ def test_engine_bf16_at_the_benchmarked_row_count(monkeypatch):
     torch.cuda.empty_cache()
     model = _build(torch.bfloat16)
     eng = TrainEngine(model, lr=1e-4)
-    persistent, tiles = [], set()
+    persistent, half_cu, tiles = [], [], set()
     real_gemm, real_grouped = nnops.gemm, nnops.gemm_grouped
     grouped_tiles = []
 
@@ -364,7 +364,9 @@ def test_engine_bf16_at_the_benchmarked_row_count(monkeypatch):
         if tile is None and nnops.gemm_mfma_ok(a, b, out, layout, bias):
             t = nnops.pick_tile(M, N, K)
             tiles.add(nnops.TILE_NAMES[t])
-            if nnops.persistent_pays(t, M, N, K, layout, accumulate):
+            if nnops.half_cu_pays(M, N, K, layout, accumulate):
+                half_cu.append((layout, M, N, K))
+            elif nnops.persistent_pays(t, M, N, K, layout, accumulate):
                 persistent.append((layout, M, N, K))
         return real_gemm(a, b, layout, bias=bias, out=out, accumulate=accumulate, tile=tile)
 
@@ -377,11 +379,14 @@ def test_engine_bf16_at_the_benchmarked_row_count(monkeypatch):
     out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
     torch.cuda.synchronize()
     routes = {k: v - before[k] for k, v in nnops.GEMM_ROUTES.items()}
-    print("8192 rows: persistent", persistent, "tiles", sorted(tiles), "grouped", grouped_tiles, "routes", routes)
+    print("8192 rows: two-per-CU tile", half_cu, "persistent", persistent, "tiles", sorted(tiles), "grouped", grouped_tiles, "routes", routes)
     assert routes["any"] == 0 and routes["tn_padded"] == 0 and routes["row_split"] == 0
-    assert persistent.count(("nt", 8192, 2304, 768)) == 4, persistent            # the QKV projection of every layer (2 + 2)
-    # (the all-layer cross-K/V projection is [8192, L * 1536]: persistent at the benchmark's 12 layers -- tests/test_gemm2_gpu.py
-    #  runs that shape -- while the 2 layers of this model give a CU fewer than three tiles)
+    # round 5: the QKV projection of every layer (2 + 2) and this model's all-layer cross-K/V projection ([8192, 2 * 1536]: four
+    # 128 x 192 tiles per CU) run on the four-wave tile, two workgroups per CU (nnops.half_cu_pays; rounds 3 - 4: persistent kernel)
+    assert half_cu.count(("nt", 8192, 2304, 768)) == 4 and ("nt", 8192, 2 * 1536, 768) in half_cu, half_cu
+    # (the all-layer cross-K/V projection of the benchmark's 12 layers is [8192, 18432]: 24 such tiles per CU -- persistent
+    #  256 x 256 kernel; tests/test_gemm2_gpu.py runs that shape)
+    assert not nnops.half_cu_pays(8192, 12 * 1536, 768, "nt")
     assert nnops.persistent_pays(nnops.pick_tile(8192, 12 * 1536, 768), 8192, 12 * 1536, 768, "nt")
     assert any(t == "256x256" for _, t in grouped_tiles)                          # two layers' weight gradients in one round of the CUs
     np.testing.assert_allclose(out["loss_recon"].item(), ref["loss_recon"], rtol=2e-2)

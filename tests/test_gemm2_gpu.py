@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TILES = ["128x192", "128x256", "256x192", "256x256", "64x128"]
+TILES = ["128x192", "128x256", "256x192", "256x256", "64x128", "128x192h"]
 
 
 def _ops(layout, M, N, K, seed=0, lda_pad=0):
@@ -131,7 +131,7 @@ def _gelu(x):
     return torch.nn.functional.gelu(x)
 
 
-@pytest.mark.parametrize("tile", ["256x192", "128x256"])
+@pytest.mark.parametrize("tile", ["256x192", "128x256", "128x192h"])
 def test_gemm_gelu_epilogue(tile):
     """BertIntermediate (modeling_bert.py:325-337): h = x W^T + b and gelu(h) from one kernel."""
     from kvq import nnops
