@@ -236,6 +236,24 @@ def main():
         pack_elapsed = time.perf_counter() - tp
     vq_ms = sorted(buf[i] for i in range(n_ev))
     vq_avg_ms = sum(vq_ms) / max(len(vq_ms), 1) if vq_ms else float("nan")
+    # the distance / arg-min phase alone: a few more steps with the quantiser forward split into its three kernels again
+    # (kvq_vq_set_variant(0): the quantiser forward is an eager interlude between the step's graphs, so nothing is re-captured);
+    # the event pair then brackets the distance kernel only -- same code, same operands, same place in the step
+    dist_phase_ms = None
+    if engine is not None and vq is not None and not grouped and os.environ.get("KVQ_VQ_FUSED", "1") != "0" and n_ev:
+        lib.kvq_vq_set_variant(0)
+        one_step(a.warmup + a.steps)
+        torch.cuda.synchronize()
+        lib.kvq_prof_enable(12)
+        for i in range(8):
+            one_step(a.warmup + a.steps + 1 + i)
+        torch.cuda.synchronize()
+        b2 = (ctypes.c_float * 12)()
+        n2 = lib.kvq_prof_read(b2, 12)
+        lib.kvq_prof_enable(0)
+        lib.kvq_vq_set_variant(1)
+        if n2:
+            dist_phase_ms = sum(b2[i] for i in range(n2)) / n2
 
     clock_mhz, clock_per_xcd = nnops.clock_mhz(probe0, probe1)
     # kernel time per family: a few EAGER steps after the timed region with an event pair around every entry point of libkvq.so
@@ -351,6 +369,13 @@ def main():
                 "frac_at_clock": (ach_tflops / (F32_MFMA_PEAK_TFLOPS * at_clock)) if (ach_tflops and at_clock) else None,
                 "traffic": traffic, "traffic_source": "profiles/vq_fwd_traffic.json (rocprofv3 --pmc pass of this kernel, not this run)",
                 "avg_launch_us": vq_avg_ms * 1e3 if vq_ms else None, "launches": len(vq_ms),
+                # the matrix phase of the same kernel, timed in 8 further steps of this run with the tail split off again
+                # (profiles/r05_vq_fused.md): what `frac` read in rounds 1 - 4, when the launch held nothing else
+                "distance_phase": ({"avg_launch_us": dist_phase_ms * 1e3, "achieved": flops / (dist_phase_ms * 1e-3) / 1e12,
+                                    "frac": flops / (dist_phase_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                    "frac_at_clock": (flops / (dist_phase_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TFLOPS * at_clock)) if at_clock else None,
+                                    "method": "8 steps after the timed region with kvq_vq_set_variant(0): event pair around the distance / arg-min kernel alone"}
+                                   if dist_phase_ms else None),
                 "flops_per_launch": flops, "algorithmic_bytes_per_launch": dist_alg, "fabric_floor_bytes_per_launch": dist_floor,
                 "forward": {"algorithmic_bytes": alg_bytes, "traffic": sum(fwd_traffic.values()) if fwd_traffic else None,
                             "kernels": fwd_traffic},

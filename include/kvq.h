@@ -320,7 +320,8 @@ int kvq_attn_set_variant(int variant);
 #define KVQ_GEMM_TILE_64x128 4    /* 4 waves, two workgroups per CU: outputs too small to give every CU a larger tile (the reference's own
                                    * batches: 12 tokens x 64..128 sentences, models/shelgon3/Trainer.py:82) */
 #define KVQ_GEMM_TILE_128x192H 5  /* 4 waves, two ring slots, 80 KiB: TWO workgroups per CU (one wave per SIMD each) whose start-up and
-                                   * epilogue run under the other's k loop; for outputs of >= 512 such tiles */
+                                   * epilogue run under the other's k loop.  Round-5 experiment: ahead on hot operands, behind inside the
+                                   * training step (profiles/r05_gemm_ceiling.md); no caller picks it by itself */
 /* OR-ed into `tile` (layout NT, one problem, no accumulate, M and N at least one tile, K >= 192): the PERSISTENT form -- one
  * workgroup per CU walks its tiles, the k-tiles of successive tiles form one uninterrupted LDS-DMA stream and the epilogue
  * goes from the accumulator registers straight to memory; pays when a CU owns two or more tiles. */
@@ -345,7 +346,14 @@ int kvq_gemm_any_bf16(const void* A, const void* B, const void* bias, void* C, i
 int kvq_gemm_grouped_bf16(const kvq_gemm_problem* problems, int n_problems, int layout, int tile, void* stream);
 /* BertIntermediate in one kernel (modeling_bert.py:325-337), layout NT: Hout = A.B^T + bias (kept for backward) and
  * Aout = gelu(Hout as rounded to bf16) -- exact-erf GELU (erf to 1.2e-7).  tile: KVQ_GEMM_TILE_256x192 or _128x256 (optionally
- * | KVQ_GEMM_PERSISTENT) or KVQ_GEMM_TILE_128x192H. */
+ * | KVQ_GEMM_PERSISTENT). */
+/* The dense layer in front of a residual LayerNorm (BertSelfOutput / BertOutput, modeling_bert.py:282-296, 339-352), layout NT:
+ * C = dropout(A.B^T + bias, p_drop) + R, rounded as kvq_dropout_residual_ln_fwd rounds its `pre` (the dense output to bf16, times the
+ * keep scale, plus the residual, to bf16) and with ITS masks (seed + the kvq_set_seed_offset word, `site`, element index): C is
+ * bit for bit the `pre` that kernel would store, so LayerNorm forward becomes kvq_dropout_residual_ln_fwd(C, NULL, p = 0) -- half the
+ * bytes -- and backward is unchanged.  R: [M, N] bf16, row stride ldc.  tile: KVQ_GEMM_TILE_128x192, _128x256 or _64x128. */
+int kvq_gemm_bf16_dropres(const void* A, const void* B, const void* bias, const void* R, void* C, int M, int N, int K, int lda, int ldb,
+                          int ldc, int tile, float p_drop, uint64_t seed, uint32_t site, void* stream);
 int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hout, void* Aout, int M, int N, int K, int lda, int ldb,
                        int ldc, int tile, void* stream);
 /* Its backward through the activation, layout NN: C = (A.B) * gelu'(H)  (A = gradient of BertOutput.dense's output, B = its

@@ -116,6 +116,41 @@ struct IO<KVQ_BF16> {
     __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 };
 
+// Philox4x32-10 (Salmon et al. 2011).  One call -> 4 x 32 random bits for counter (c0..c3), key (k0,k1).
+struct U4 {
+    unsigned x, y, z, w;
+};
+__device__ __forceinline__ U4 philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+// keep-mask for 4 consecutive elements starting at element index e4*4 of dropout site `site`
+__device__ __forceinline__ U4 drop_bits(unsigned long long seed, unsigned site, unsigned long long e4) {
+    return philox4x32((unsigned)e4, (unsigned)(e4 >> 32), site, 0x5eedu, (unsigned)seed, (unsigned)(seed >> 32));
+}
+__device__ __forceinline__ float keep_scale(unsigned bits, unsigned thresh, float inv_keep) {
+    return bits >= thresh ? inv_keep : 0.f;   // P(drop) = thresh / 2^32
+}
+static inline unsigned drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (unsigned)t;
+}
+
+// device-resident addend of every dropout seed (kvq_set_seed_offset, per calling thread; csrc/kvq_nn.hip)
+const unsigned long long* seed_offset_ptr();
+
 // ---- wave-level reductions (64 lanes) ------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll

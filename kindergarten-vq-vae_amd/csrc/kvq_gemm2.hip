@@ -65,9 +65,15 @@ struct Problem {
     int vlimit;                        // EPI_CE: columns >= vlimit (vocabulary padding) do not take part
     const float* scaleA;               // fp8 kernel: per-tensor quantisation scales of the two operands (device scalars)
     const float* scaleB;
+    // EPI_DROPRES: C = dropout(A.B + bias) + R, R = H ([M, N], row stride ldc) -- the input of the LayerNorm behind a BertSelfOutput /
+    // BertOutput dense (modeling_bert.py:282-296, 339-352), with the masks of csrc/kvq_nn.hip's drln kernels (same Philox stream)
+    unsigned long long seed;
+    const unsigned long long* seed_off;
+    unsigned site, thresh;
+    float inv_keep;
 };
 
-constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_CE = 3;
+constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_CE = 3, EPI_DROPRES = 4;
 
 // A/B switch of the one-tile-per-workgroup kernels' prologue (round 5; -DKVQ_G2_EARLY=0 builds the round-4 form)
 #ifndef KVQ_G2_EARLY
@@ -425,9 +431,11 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
     const int n = n0 + c16 * 8;
     const bool colok = c16 < CPR && n < pr.N;                              // N % 8 == 0: a chunk is inside or outside as a whole
     const bool accum = EPI == EPI_NONE && pr.accumulate != 0;
-    const unsigned short* auxp = EPI == EPI_DGELU ? pr.H : pr.C;
+    const unsigned short* auxp = (EPI == EPI_DGELU || EPI == EPI_DROPRES) ? pr.H : pr.C;
     uint4 aux[NIT];
-    if (EPI == EPI_DGELU || accum) {
+    unsigned long long dseed = 0;
+    if constexpr (EPI == EPI_DROPRES) dseed = pr.seed + (pr.seed_off ? *pr.seed_off : 0ull);      // (scalar load, waited for in the store loop)
+    if (EPI == EPI_DGELU || EPI == EPI_DROPRES || accum) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int m = m0 + rr + it * C::RPP;
@@ -528,6 +536,27 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
                 for (int u = 0; u < 4; ++u) {
                     const float lo = __uint_as_float(vn[u] << 16) + __uint_as_float(vo[u] << 16);
                     const float hi = __uint_as_float(vn[u] & 0xffff0000u) + __uint_as_float(vo[u] & 0xffff0000u);
+                    vn[u] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                }
+            }
+            if constexpr (EPI == EPI_DROPRES) {
+                // what drln_fwd_kernel does with the dense output y (here: the bf16 values of the LDS tile) and the residual, in
+                // its order: y * keep-scale, + residual, rounded to the io dtype.  One Philox call covers 4 consecutive elements
+                // of a row, counted row * N/4 + chunk.
+                const unsigned* rv = reinterpret_cast<const unsigned*>(&aux[it]);
+                float ks[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+                if (pr.thresh != 0) {                                      // (uniform: no dropout, no Philox rounds -- they are NOT free here)
+                    const unsigned long long e4 = (unsigned long long)m * (unsigned)(pr.N >> 2) + (unsigned)(n >> 2);
+                    const U4 k0 = drop_bits(dseed, pr.site, e4), k1 = drop_bits(dseed, pr.site, e4 + 1);
+                    ks[0] = keep_scale(k0.x, pr.thresh, pr.inv_keep); ks[1] = keep_scale(k0.y, pr.thresh, pr.inv_keep);
+                    ks[2] = keep_scale(k0.z, pr.thresh, pr.inv_keep); ks[3] = keep_scale(k0.w, pr.thresh, pr.inv_keep);
+                    ks[4] = keep_scale(k1.x, pr.thresh, pr.inv_keep); ks[5] = keep_scale(k1.y, pr.thresh, pr.inv_keep);
+                    ks[6] = keep_scale(k1.z, pr.thresh, pr.inv_keep); ks[7] = keep_scale(k1.w, pr.thresh, pr.inv_keep);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float lo = __uint_as_float(vn[u] << 16) * ks[2 * u] + __uint_as_float(rv[u] << 16);
+                    const float hi = __uint_as_float(vn[u] & 0xffff0000u) * ks[2 * u + 1] + __uint_as_float(rv[u] & 0xffff0000u);
                     vn[u] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
                 }
             }
@@ -1246,6 +1275,7 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
             d.mg_rem = mg(along % w ? along % w : w);
         }
         d.C2 = nullptr; d.H = nullptr; d.part = nullptr; d.vlimit = 0; d.scaleA = nullptr; d.scaleB = nullptr;
+        d.seed = 0; d.seed_off = nullptr; d.site = 0; d.thresh = 0; d.inv_keep = 1.0f;
         t0 += d.tiles_m * d.tiles_n;
     }
     for (int i = nprob; i < g2::MAX_PROBLEMS; ++i) P.p[i] = P.p[0];
@@ -1295,8 +1325,7 @@ int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hou
                        int ldc, int tile, void* stream) {
     KVQ_REQUIRE(Aout && ((uintptr_t)Aout & 15) == 0, "kvq_gemm_bf16_gelu: null / misaligned second output");
     const int base = tile & ~KVQ_GEMM_PERSISTENT;
-    KVQ_REQUIRE(base == KVQ_GEMM_TILE_256x192 || base == KVQ_GEMM_TILE_128x256 || tile == KVQ_GEMM_TILE_128x192H,
-                "kvq_gemm_bf16_gelu: tile must be 256x192, 128x256 (optionally persistent) or 128x192H");
+    KVQ_REQUIRE(base == KVQ_GEMM_TILE_256x192 || base == KVQ_GEMM_TILE_128x256, "kvq_gemm_bf16_gelu: tile must be 256x192 or 128x256");
     kvq_gemm_problem q;
     q.A = A; q.B = B; q.C = Hout; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.accumulate = 0;
     g2::Params P;
@@ -1307,9 +1336,29 @@ int kvq_gemm_bf16_gelu(const void* A, const void* B, const void* bias, void* Hou
         if (base == KVQ_GEMM_TILE_256x192) return g2::launch_persistent<g2::Cfg256x192<true, true>, g2::EPI_GELU>(P, st);
         return g2::launch_persistent<g2::Cfg128x256<true, true>, g2::EPI_GELU>(P, st);
     }
-    if (tile == KVQ_GEMM_TILE_128x192H) return g2::launch_cfg<g2::Cfg128x192h<true, true>, g2::EPI_GELU>(P, st);
     if (tile == KVQ_GEMM_TILE_256x192) return g2::launch_cfg<g2::Cfg256x192<true, true>, g2::EPI_GELU>(P, st);
     return g2::launch_cfg<g2::Cfg128x256<true, true>, g2::EPI_GELU>(P, st);
+}
+
+int kvq_gemm_bf16_dropres(const void* A, const void* B, const void* bias, const void* R, void* C, int M, int N, int K, int lda, int ldb,
+                          int ldc, int tile, float p_drop, uint64_t seed, uint32_t site, void* stream) {
+    KVQ_REQUIRE(R && ((uintptr_t)R & 15) == 0, "kvq_gemm_bf16_dropres: null / misaligned residual");
+    KVQ_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "kvq_gemm_bf16_dropres: p_drop out of range");
+    KVQ_REQUIRE(tile == KVQ_GEMM_TILE_128x192 || tile == KVQ_GEMM_TILE_128x256 || tile == KVQ_GEMM_TILE_64x128,
+                "kvq_gemm_bf16_dropres: tile must be 128x192, 128x256 or 64x128");
+    kvq_gemm_problem q;
+    q.A = A; q.B = B; q.C = C; q.bias = bias; q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.accumulate = 0;
+    g2::Params P;
+    if (int rc = build_params(&q, 1, KVQ_GEMM_NT, tile, P, "kvq_gemm_bf16_dropres")) return rc;
+    for (int i = 0; i < g2::MAX_PROBLEMS; ++i) {
+        g2::Problem& d = P.p[i];
+        d.H = (const unsigned short*)R; d.seed = seed; d.seed_off = seed_offset_ptr(); d.site = site; d.thresh = drop_threshold(p_drop);
+        d.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (tile == KVQ_GEMM_TILE_128x256) return g2::launch_cfg<g2::Cfg128x256<true, true>, g2::EPI_DROPRES>(P, st);
+    if (tile == KVQ_GEMM_TILE_64x128) return g2::launch_cfg<g2::Cfg64x128<true, true>, g2::EPI_DROPRES>(P, st);
+    return g2::launch_cfg<g2::Cfg128x192<true, true>, g2::EPI_DROPRES>(P, st);
 }
 
 size_t kvq_gemm_ce_stats_bytes(int M, int N) { return (size_t)(M > 0 ? M : 0) * (size_t)((N + 255) / 256) * 16; }

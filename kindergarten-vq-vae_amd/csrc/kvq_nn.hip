@@ -20,46 +20,16 @@
 
 namespace kvq {
 
-// ---------------------------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011).  One call -> 4 x 32 random bits for counter (c0..c3), key (k0,k1).
-// ---------------------------------------------------------------------------------------------------------------
-struct U4 {
-    unsigned x, y, z, w;
-};
-__device__ __forceinline__ U4 philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
-        const unsigned n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
-        const unsigned n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return {c0, c1, c2, c3};
-}
-// keep-mask for 4 consecutive elements starting at element index e4*4 of dropout site `site`
-__device__ __forceinline__ U4 drop_bits(unsigned long long seed, unsigned site, unsigned long long e4) {
-    return philox4x32((unsigned)e4, (unsigned)(e4 >> 32), site, 0x5eedu, (unsigned)seed, (unsigned)(seed >> 32));
-}
-__device__ __forceinline__ float keep_scale(unsigned bits, unsigned thresh, float inv_keep) {
-    return bits >= thresh ? inv_keep : 0.f;   // P(drop) = thresh / 2^32
-}
-static inline unsigned drop_threshold(float p) {
-    double t = (double)p * 4294967296.0;
-    if (t < 0) t = 0;
-    if (t > 4294967295.0) t = 4294967295.0;
-    return (unsigned)t;
-}
+// (Philox4x32-10, drop_bits, keep_scale, drop_threshold: kvq_common.h -- the GEMM epilogue of csrc/kvq_gemm2.hip draws the same masks)
 
 // ---------------------------------------------------------------------------------------------------------------
 // LN(dropout(y) + residual): one wave per row, rows of H <= 4096 (H % 4 == 0); bf16 or f32 io
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int LN_MAX_PER_LANE = 16;   // H <= 64 * 4 * 16 = 4096
 
-template <int DT, int PER>
+// RES = false (round 5): no residual operand at all -- the LayerNorm-only pass behind kvq_gemm_bf16_dropres, whose GEMM epilogue
+// already added the residual: one load stream instead of two.
+template <int DT, int PER, bool RES = true>
 __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ y, const void* __restrict__ resid,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int64_t N, int H, float eps, float p_drop, unsigned thresh,
@@ -80,13 +50,13 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
     const void* rp = resid ? resid : y;
     const float rw = resid ? 1.0f : 0.0f;
     constexpr bool EARLY_GB = PER <= 4;        // (wide rows: gamma / beta stay L2-resident small loads of the last pass)
-    f32x4 v[PER], r[PER], g[EARLY_GB ? PER : 1], b[EARLY_GB ? PER : 1];
+    f32x4 v[PER], r[RES ? PER : 1], g[EARLY_GB ? PER : 1], b[EARLY_GB ? PER : 1];
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int c = lane + WAVE * t < nchunk ? lane + WAVE * t : nchunk - 1;
         const size_t off = (size_t)row * H + 4 * c;
         v[t] = IO<DT>::load4(y, off);
-        r[t] = IO<DT>::load4(rp, off);
+        if constexpr (RES) r[t] = IO<DT>::load4(rp, off);
     }
     if constexpr (EARLY_GB) {
 #pragma unroll
@@ -108,7 +78,7 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
             a.x *= keep_scale(kb.x, thresh, inv_keep); a.y *= keep_scale(kb.y, thresh, inv_keep);
             a.z *= keep_scale(kb.z, thresh, inv_keep); a.w *= keep_scale(kb.w, thresh, inv_keep);
         }
-        a += r[t] * rw;
+        if constexpr (RES) a += r[t] * rw;
         // LayerNorm sees the STORED pre-activation (bf16-rounded when io is bf16): backward re-reads exactly that
         a.x = IO<DT>::round(a.x); a.y = IO<DT>::round(a.y); a.z = IO<DT>::round(a.z); a.w = IO<DT>::round(a.w);
         if (c < nchunk) {
@@ -2435,6 +2405,9 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges z) {
 using namespace kvq;
 
 static thread_local const unsigned long long* g_seed_off = nullptr;   // kvq_set_seed_offset: per calling thread (two engines on two threads do not see each other's)
+namespace kvq {
+const unsigned long long* seed_offset_ptr() { return g_seed_off; }       // (for the dropout epilogue of csrc/kvq_gemm2.hip)
+}
 
 #define DISPATCH_DT(dt, CALL_F32, CALL_BF16) \
     do {                                     \
@@ -2477,6 +2450,10 @@ int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* g
 #define LAUNCH_LN_FWD(DTV, PERV)                                                                                          \
     hipLaunchKernelGGL((drln_fwd_kernel<DTV, PERV>), grid, dim3(256), 0, st, y, resid, gamma, beta, N, H, eps, p_drop, th, \
                        (unsigned long long)seed, g_seed_off, site, out, pre, mean, rstd)
+    if (!resid && H <= 768 && io_dtype == KVQ_BF16) {          // LayerNorm alone (the dense layer's epilogue added the residual)
+        hipLaunchKernelGGL((drln_fwd_kernel<KVQ_BF16, 3, false>), grid, dim3(256), 0, st, y, resid, gamma, beta, N, H, eps, p_drop, th,
+                           (unsigned long long)seed, g_seed_off, site, out, pre, mean, rstd);
+    } else
     if (H <= 768) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 3), LAUNCH_LN_FWD(KVQ_BF16, 3)); }
     else if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 4), LAUNCH_LN_FWD(KVQ_BF16, 4)); }
     else { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 16), LAUNCH_LN_FWD(KVQ_BF16, 16)); }

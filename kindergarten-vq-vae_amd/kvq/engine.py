@@ -392,6 +392,12 @@ class TrainEngine:
             self._TILE_OVERRIDE = {tuple(int(v) for v in e.split(":")[0].split("x")): e.split(":")[1]
                                    for e in os.environ["KVQ_GEMM_TILE"].split(";") if e}
         self._own_epi = os.environ.get("KVQ_OWN_EPI", "1") != "0"     # A/B switch: 0 = activations as separate kernels behind the GEMMs
+        # round 5: dropout + residual of a BertSelfOutput / BertOutput block in the dense layer's epilogue, LayerNorm alone behind it
+        # (8.2 us instead of 11.9: one tensor read, one written).  Bit-identical -- and only worth it WITHOUT dropout: the Philox
+        # rounds of 6 M elements are ~5 us of vector-ALU time per SIMD, which the LayerNorm kernel hides behind its loads and a
+        # GEMM epilogue does not (same-box traces, profiles/r05_gemm_ceiling.md: +7 us per GEMM against -3.7 us per LayerNorm).
+        # "eval" (default): steps without dropout (validation / test stages, model.forward); "1": always (tests); "0": never.
+        self._fuse_dropres = os.environ.get("KVQ_FUSE_DROPRES", "eval")
         # weight gradients of a whole layer as ONE grouped launch of csrc/kvq_gemm2.hip (KVQ_OWN_WGRAD=0: library + split-K slabs)
         self._own_wgrad = self._own_fwd and os.environ.get("KVQ_OWN_WGRAD", "1") != "0" and self.dtype == torch.bfloat16
         self._wg_items, self._wg_keep = [], []
@@ -413,12 +419,6 @@ class TrainEngine:
         self.wg_stream = torch.cuda.Stream(device=dev) if os.environ.get("KVQ_WG_STREAM", "0") == "1" else None
         self._wg_pending = False
         self._wg_keep_step = []
-        # opt-in (KVQ_RED_STREAM=1, round 5 experiment): the batched small reductions (bias / LayerNorm partial rows -> gradient
-        # buffer: 14 launches of ~16 us per step, nothing in backward reads their results) on a side stream, joined where the
-        # weight gradients are.  profiles/r05_gemm_ceiling.md has the A/B.
-        self.red_stream = torch.cuda.Stream(device=dev) if os.environ.get("KVQ_RED_STREAM", "0") == "1" else None
-        self._red_pending = False
-        self._red_keep_step = []
         self.use_graph = os.environ.get("KVQ_GRAPH", "1") != "0"
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -704,16 +704,31 @@ class TrainEngine:
         return torch.addmm(bias, A, Bm) if bias is not None else torch.mm(A, Bm)
 
     def _epilogue_tile(self, M, N, K):
-        """Tile of the fused-activation GEMMs (they exist for 256 x 192, 128 x 256 and the two-per-CU 128 x 192), or None when the plain GEMM on its best
+        """Tile of the fused-activation GEMMs (they exist for 256 x 192 and 128 x 256), or None when the plain GEMM on its best
         tile + the separate activation kernel (one pass over [M, N]: ~3 us + 4 bytes per element at ~3 TB/s) is modelled cheaper --
         outputs too small to give half the CUs one of the large tiles."""
         if not (self._own_fwd and self._own_epi and self.dtype == torch.bfloat16):
             return None
-        if nnops.half_cu_pays(M, N, K, "nt"):
-            return "128x192h"
         t = nnops.pick_tile(M, N, K, candidates=("256x192", "128x256"))
         plain = nnops.tile_cost_us(nnops.pick_tile(M, N, K), M, N, K) + 3.0 + M * N * 4 / 3e6
         return nnops.TILE_NAMES[t] if nnops.tile_cost_us(t, M, N, K) <= plain else None
+
+    def _dense_residual_ln(self, a, wname, bname, resid, gname, betaname, eps, p_drop, site):
+        """LayerNorm(dropout(a . W^T + b) + resid) of a BertSelfOutput / BertOutput block (modeling_bert.py:282-296, 339-352):
+        (out, pre, mean, rstd) as nnops.ln_fwd returns them.  bf16 engine: the dense layer's epilogue draws the dropout mask, adds
+        the residual and stores `pre` (nnops.gemm_dropres -- bit for bit the `pre` of the two-kernel form), then LayerNorm alone."""
+        fl = self.flat
+        W, b = fl.w(wname), fl.w(bname)
+        gamma, beta = fl.w32(gname), fl.w32(betaname)
+        if (self._fuse_dropres == "1" or (self._fuse_dropres == "eval" and p_drop == 0.0)) and self._own_fwd and self._own_epi \
+                and self.dtype == torch.bfloat16 \
+                and not (self.fp8 and wname in self._w8_index) and a.is_contiguous() and resid.is_contiguous() \
+                and nnops.gemm_mfma_ok(a, W, None, "nt", b):
+            pre = nnops.gemm_dropres(a, W, b, resid, p_drop, self._step_seed, site)
+            out, _, mean, rstd = nnops.ln_fwd(pre, None, gamma, beta, eps, 0.0, 0, 0, save_pre=False)
+            return out, pre, mean, rstd
+        y = self._linear(a, wname, bname)
+        return nnops.ln_fwd(y, resid, gamma, beta, eps, p_drop, self._step_seed, site)
 
     def _linear_gelu(self, x, wname, bname):
         """(h, gelu(h)), h = x . W^T + b: one kernel where the own GEMM carries the activation in its epilogue."""
@@ -772,10 +787,6 @@ class TrainEngine:
             torch.cuda.current_stream(self.dev).wait_stream(self.wg_stream)
             self._wg_pending = False
         self._wg_keep_step = []
-        if self._red_pending:
-            torch.cuda.current_stream(self.dev).wait_stream(self.red_stream)
-            self._red_pending = False
-        self._red_keep_step = []
 
     def _flush_reductions(self, force=True):
         """Launch the queued batched reductions and (see _flush_wgrads) the queued weight gradients; True if none stay queued."""
@@ -783,14 +794,8 @@ class TrainEngine:
         if not done and self._red_pair:
             return False                       # ... and the small sums wait with them: one launch per two layers as well
         if self._red_items:
-            if self.red_stream is not None:
-                self.red_stream.wait_stream(torch.cuda.current_stream(self.dev))
-                with torch.cuda.stream(self.red_stream):
-                    nnops.reduce_batch(self._red_items)
-                self._red_pending = True
-                self._red_keep_step += self._red_keep       # the partial rows stay alive until the join
-            else:
-                nnops.reduce_batch(self._red_items)
+            nnops.reduce_batch(self._red_items)       # (round 5: on a side stream, joined with the weight gradients, the step was
+                                                      #  0.5 ms SLOWER -- profiles/r05_gemm_ceiling.md)
         self._red_items, self._red_keep = [], []
         return done
 
@@ -960,9 +965,8 @@ class TrainEngine:
                 self._linear(kv_src, None, None, fused=([pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"]))
             q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
         ctx, lse = nnops.attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a)
-        ao = self._linear(ctx, pre + "o.w", pre + "o.b")
-        out, lnpre, mean, rstd = nnops.ln_fwd(ao, x, fl.w32(pre + "ln.w"), fl.w32(pre + "ln.b"), cfg.layer_norm_eps,
-                                              p_hid, self._step_seed, site_o)
+        out, lnpre, mean, rstd = self._dense_residual_ln(ctx, pre + "o.w", pre + "o.b", x, pre + "ln.w", pre + "ln.b", cfg.layer_norm_eps,
+                                                         p_hid, site_o)
         # (lse: only the kernels above 32 tokens work from the saved log-sum-exp)
         return out, (x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk,
                      lse if max(Sq, Sk) > 32 else None)
@@ -1016,9 +1020,8 @@ class TrainEngine:
         p_hid = cfg.hidden_dropout_prob if training else 0.0
         site = self._site()
         h, a = self._linear_gelu(x, pre + "f1.w", pre + "f1.b")
-        f = self._linear(a, pre + "f2.w", pre + "f2.b")
-        out, lnpre, mean, rstd = nnops.ln_fwd(f, x, fl.w32(pre + "ln2.w"), fl.w32(pre + "ln2.b"), cfg.layer_norm_eps,
-                                              p_hid, self._step_seed, site)
+        out, lnpre, mean, rstd = self._dense_residual_ln(a, pre + "f2.w", pre + "f2.b", x, pre + "ln2.w", pre + "ln2.b", cfg.layer_norm_eps,
+                                                         p_hid, site)
         return out, (x, h, a, lnpre, mean, rstd, p_hid, site)
 
     def _ffn_bwd(self, pre, g_out, saved):

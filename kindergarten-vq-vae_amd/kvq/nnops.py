@@ -2,7 +2,6 @@
 the training engine (kvq/engine.py) calls forward and backward kernels explicitly.  All work goes to the current stream."""
 from __future__ import annotations
 
-import os
 import torch
 
 from ._ffi import KvqError, check, io_dtype_of, lib, require_gpu, stream_ptr
@@ -278,6 +277,10 @@ def embed_grad(g, perm, sorted_ids, gW, accumulate=False):
 
 # ---- the GEMM family of csrc/kvq_gemm2.hip ---------------------------------------------------------------------------------
 _LAYOUTS = {"nt": 0, "nn": 1, "tn": 2}
+# "128x192h" (round 5): four waves, two ring slots, TWO workgroups per CU.  Faster than the persistent / 256 x 192 kernels on hot
+# operands ([8192, 2304] x 768: 34.5 against 37.0 us; [8192, 3072]: 39.6 against 41.6) and slower inside the step, where the operands
+# are cold and one k-tile of prefetch is not enough (QKV 35.6 against 31.9 us): kept as an explicit choice, not in pick_tile's set
+# (profiles/r05_gemm_ceiling.md)
 TILES = {"128x192": 0, "128x256": 1, "256x192": 2, "256x256": 3, "64x128": 4, "128x192h": 5,
          "128x192p": 0x100, "128x256p": 0x101, "256x192p": 0x102, "256x256p": 0x103}      # p: KVQ_GEMM_PERSISTENT (layout nt only)
 TILE_NAMES = {v: k for k, v in TILES.items()}
@@ -333,21 +336,6 @@ def persistent_pays(t, M, N, K, layout, accumulate=False, n_cu=256):
         return False
     per_cu = -(-(-(-M // bm) * -(-N // bn)) // n_cu)
     return 3 <= per_cu <= 12
-
-
-_HALF_CU = os.environ.get("KVQ_HALF_CU", "1") != "0"          # A/B switch of the rule below (tools/, same-box runs)
-
-
-def half_cu_pays(M, N, K, layout, accumulate=False, n_cu=256):
-    """The four-wave 128 x 192 tile that runs TWO workgroups per CU ("128x192h": one's start-up and epilogue under the other's
-    k loop) instead of pick_tile()'s choice: forward ("nt") products of a short contraction whose output is 2 .. 8 such tiles per
-    CU.  Measured at 8192 rows (tools/gemm2_probe_h.py, profiles/r05_gemm_ceiling.md): [8192, 2304] x 768 34.5 us against 37.0
-    (persistent 128 x 192) and 38.7 (256 x 192); [8192, 3072] x 768 39.6 against 41.6 (256 x 192); it loses on the wide outputs
-    (LM head, all-layer cross-K/V: the 256 x 256 tile stages fewer bytes per flop), on one tile per CU and on K >= 2304."""
-    if layout != "nt" or accumulate or K // 64 > 16 or M < 128 or N < 192 or not _HALF_CU:
-        return False
-    per_cu = (-(-M // 128) * -(-N // 192)) / n_cu
-    return 2.0 <= per_cu <= 8.0
 
 
 def gemm_mfma_ok(a, b, out, layout, bias=None):
@@ -452,9 +440,7 @@ def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
         return _gemm_any(a, b, layout, bias, out, accumulate)
     if tile is None:
         t = pick_tile(M, N, K)
-        if half_cu_pays(M, N, K, layout, accumulate):
-            t = TILES["128x192h"]
-        elif persistent_pays(t, M, N, K, layout, accumulate):
+        if persistent_pays(t, M, N, K, layout, accumulate):
             t |= 0x100
     else:
         t = TILES[tile] if isinstance(tile, str) else tile
@@ -481,6 +467,27 @@ def gemm_gelu(x, w, bias, tile="256x192"):
     check(lib().kvq_gemm_bf16_gelu(x.data_ptr(), w.data_ptr(), _p(bias), h.data_ptr(), a.data_ptr(), M, N, K, x.stride(0), w.stride(0),
                                    h.stride(0), TILES[tile], stream_ptr()), "kvq_gemm_bf16_gelu")
     return h, a
+
+
+DROPRES_TILES = ("128x192", "128x256", "64x128")
+
+
+def gemm_dropres(x, w, bias, resid, p_drop, seed, site, tile=None):
+    """pre = dropout(x @ w.T + bias, p_drop) + resid in one kernel: the LayerNorm input of BertSelfOutput / BertOutput
+    (modeling_bert.py:282-296, 339-352), bit for bit what ln_fwd(x @ w.T + bias, resid, ..., p_drop, seed, site) stores as `pre`
+    (same roundings, same Philox masks) -- so the block's forward is this + ln_fwd(pre, None, ..., p_drop=0) and its backward is
+    unchanged.  The tile comes from pick_tile() over the tiles this epilogue is built for."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert tuple(resid.shape) == (M, N) and resid.dtype == torch.bfloat16 and resid.stride(1) == 1
+    pre = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    assert resid.stride(0) == pre.stride(0)
+    t = pick_tile(M, N, K, candidates=DROPRES_TILES) if tile is None else (TILES[tile] if isinstance(tile, str) else tile)
+    GEMM_ROUTES["mfma"] += 1
+    check(lib().kvq_gemm_bf16_dropres(x.data_ptr(), w.data_ptr(), _p(bias), resid.data_ptr(), pre.data_ptr(), M, N, K, x.stride(0),
+                                      w.stride(0), pre.stride(0), t, float(p_drop), int(seed), int(site), stream_ptr()),
+          "kvq_gemm_bf16_dropres")
+    return pre
 
 
 def gemm_dgelu(gy, w, h, tile="256x192"):

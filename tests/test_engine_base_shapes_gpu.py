@@ -144,7 +144,7 @@ def test_every_own_gemm_of_the_engine_step_against_f32_matmul_of_its_operands(mo
     model = _build(torch.bfloat16)
     eng = TrainEngine(model, lr=1e-4)
     ids, mask = _batch(seed=8)
-    seen, worst = {"nt": 0, "nn": 0, "tn": 0, "gelu": 0, "dgelu": 0, "grouped": 0, "persistent": 0}, [0.0, ""]
+    seen, worst = {"nt": 0, "nn": 0, "tn": 0, "gelu": 0, "dgelu": 0, "dropres": 0, "grouped": 0, "persistent": 0}, [0.0, ""]
 
     def ref(a, b, layout):
         a, b = a.float(), b.float()
@@ -157,7 +157,7 @@ def test_every_own_gemm_of_the_engine_step_against_f32_matmul_of_its_operands(mo
         assert err < 4e-3, f"{what}: relative L2 error {err:.3g} against the f32 matmul of the same operands"     # bf16 output rounding: 2^-9
 
     real = dict(gemm=nnops.gemm, gemm_gelu=nnops.gemm_gelu, gemm_dgelu=nnops.gemm_dgelu, gemm_problem=nnops.gemm_problem,
-                gemm_grouped=nnops.gemm_grouped)
+                gemm_grouped=nnops.gemm_grouped, gemm_dropres=nnops.gemm_dropres)
     recorded = {}
 
     def gemm(a, b, layout="nt", bias=None, out=None, accumulate=False, tile=None):
@@ -183,6 +183,13 @@ def test_every_own_gemm_of_the_engine_step_against_f32_matmul_of_its_operands(mo
         seen["persistent"] += tile.endswith("p")
         return h, g
 
+    def gemm_dropres(x, w, bias, resid, p_drop, seed, site, tile=None):
+        pre = real["gemm_dropres"](x, w, bias, resid, p_drop, seed, site, tile=tile)
+        assert p_drop == 0.0                         # (this step runs with training=False: the epilogue's mask keeps everything)
+        judge(pre, (ref(x, w, "nt") + bias.float()).to(torch.bfloat16).float() + resid.float(), f"gemm_dropres {tuple(pre.shape)} K={x.shape[1]}")
+        seen["dropres"] += 1
+        return pre
+
     def gemm_dgelu(gy, w, h, tile="256x192"):
         g_h, part = real["gemm_dgelu"](gy, w, h, tile=tile)
         with torch.enable_grad():                    # (the engine runs its schedule under no_grad)
@@ -205,14 +212,17 @@ def test_every_own_gemm_of_the_engine_step_against_f32_matmul_of_its_operands(mo
             judge(out, ref(a, b, lay), f"grouped {lay} {tuple(out.shape)} tile={tile}")
             seen["grouped"] += 1
 
-    for k, f in dict(gemm=gemm, gemm_gelu=gemm_gelu, gemm_dgelu=gemm_dgelu, gemm_problem=gemm_problem, gemm_grouped=gemm_grouped).items():
+    for k, f in dict(gemm=gemm, gemm_gelu=gemm_gelu, gemm_dgelu=gemm_dgelu, gemm_problem=gemm_problem, gemm_grouped=gemm_grouped,
+                     gemm_dropres=gemm_dropres).items():
         monkeypatch.setattr(nnops, k, f)
     out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
     assert np.isfinite(out["loss_recon"].item()) and not recorded
     print("own GEMM launches checked inside the engine step:", seen, "worst:", worst)
     # 2 + 2 layers: every family ran, the persistent forward kernel (the four QKV projections) included
     # (gelu: the four FFN1 projections + the prediction head's transform, which the epilogue rule now takes as well)
-    assert seen["nt"] >= 12 and seen["nn"] >= 14 and seen["tn"] >= 1 and seen["gelu"] in (4, 5) and seen["dgelu"] == 4
+    # (dropres, round 5: the dense layers in front of the ten residual LayerNorms -- 2 per encoder layer, 3 per decoder layer -- carry
+    #  dropout + residual in their epilogue and no longer come through nnops.gemm)
+    assert seen["nt"] >= 8 and seen["dropres"] == 10 and seen["nn"] >= 14 and seen["tn"] >= 1 and seen["gelu"] in (4, 5) and seen["dgelu"] == 4
     # (persistent: at 2048 rows only the all-layer cross-K/V projection gives a CU three tiles or more; at the benchmarked 8192 rows
     #  the QKV projections run persistent as well -- nnops.persistent_pays; the persistent kernel alone: tests/test_gemm2_gpu.py)
     assert seen["grouped"] >= 20 and seen["persistent"] >= 1
@@ -342,8 +352,8 @@ def test_engine_bf16_at_bert_base_shapes_with_64_token_sentences():
 
 # ---- the benchmarked row count (round 5): B = 256 sentences x S = 32 tokens = 8192 rows, where the routing differs from 2048 rows ----
 def test_engine_bf16_at_the_benchmarked_row_count(monkeypatch):
-    """kvq-bert-base-2l, bf16, 256 x 32 tokens -- bench.py's batch: the QKV projections run on the two-workgroups-per-CU tile (round 5;
-    the persistent kernel before), which no product of the 2048-row test reaches, the grouped weight-gradient queue sees 8192-row contractions, the tile rule
+    """kvq-bert-base-2l, bf16, 256 x 32 tokens -- bench.py's batch: the QKV projections run on the PERSISTENT kernel (at 2048 rows
+    only the all-layer cross-K/V projection does), the grouped weight-gradient queue sees 8192-row contractions, the tile rule
     picks for 8192 rows.  Against f32 autograd through HuggingFace's forward, with the tolerances of the 2048-row test above."""
     from kvq import nnops
     from kvq.engine import TrainEngine
@@ -355,7 +365,7 @@ def test_engine_bf16_at_the_benchmarked_row_count(monkeypatch):
     torch.cuda.empty_cache()
     model = _build(torch.bfloat16)
     eng = TrainEngine(model, lr=1e-4)
-    persistent, half_cu, tiles = [], [], set()
+    persistent, tiles = [], set()
     real_gemm, real_grouped = nnops.gemm, nnops.gemm_grouped
     grouped_tiles = []
 
@@ -364,9 +374,7 @@ def test_engine_bf16_at_the_benchmarked_row_count(monkeypatch):
         if tile is None and nnops.gemm_mfma_ok(a, b, out, layout, bias):
             t = nnops.pick_tile(M, N, K)
             tiles.add(nnops.TILE_NAMES[t])
-            if nnops.half_cu_pays(M, N, K, layout, accumulate):
-                half_cu.append((layout, M, N, K))
-            elif nnops.persistent_pays(t, M, N, K, layout, accumulate):
+            if nnops.persistent_pays(t, M, N, K, layout, accumulate):
                 persistent.append((layout, M, N, K))
         return real_gemm(a, b, layout, bias=bias, out=out, accumulate=accumulate, tile=tile)
 
@@ -379,14 +387,11 @@ def test_engine_bf16_at_the_benchmarked_row_count(monkeypatch):
     out = eng.forward_backward(ids, mask, training=False, compute_grads=True)
     torch.cuda.synchronize()
     routes = {k: v - before[k] for k, v in nnops.GEMM_ROUTES.items()}
-    print("8192 rows: two-per-CU tile", half_cu, "persistent", persistent, "tiles", sorted(tiles), "grouped", grouped_tiles, "routes", routes)
+    print("8192 rows: persistent", persistent, "tiles", sorted(tiles), "grouped", grouped_tiles, "routes", routes)
     assert routes["any"] == 0 and routes["tn_padded"] == 0 and routes["row_split"] == 0
-    # round 5: the QKV projection of every layer (2 + 2) and this model's all-layer cross-K/V projection ([8192, 2 * 1536]: four
-    # 128 x 192 tiles per CU) run on the four-wave tile, two workgroups per CU (nnops.half_cu_pays; rounds 3 - 4: persistent kernel)
-    assert half_cu.count(("nt", 8192, 2304, 768)) == 4 and ("nt", 8192, 2 * 1536, 768) in half_cu, half_cu
-    # (the all-layer cross-K/V projection of the benchmark's 12 layers is [8192, 18432]: 24 such tiles per CU -- persistent
-    #  256 x 256 kernel; tests/test_gemm2_gpu.py runs that shape)
-    assert not nnops.half_cu_pays(8192, 12 * 1536, 768, "nt")
+    assert persistent.count(("nt", 8192, 2304, 768)) == 4, persistent            # the QKV projection of every layer (2 + 2)
+    # (the all-layer cross-K/V projection is [8192, L * 1536]: persistent at the benchmark's 12 layers -- tests/test_gemm2_gpu.py
+    #  runs that shape -- while the 2 layers of this model give a CU fewer than three tiles)
     assert nnops.persistent_pays(nnops.pick_tile(8192, 12 * 1536, 768), 8192, 12 * 1536, 768, "nt")
     assert any(t == "256x256" for _, t in grouped_tiles)                          # two layers' weight gradients in one round of the CUs
     np.testing.assert_allclose(out["loss_recon"].item(), ref["loss_recon"], rtol=2e-2)

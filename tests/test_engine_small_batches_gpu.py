@@ -17,10 +17,10 @@ from _gemm_guard import forbid_vendor_gemms as _forbid_vendor_gemms  # noqa: E40
 def _judged_gemms(monkeypatch, tol=4e-3):
     """Wrap the GEMM entry points of kvq.nnops: every launch is compared with the f32 product of its own operands."""
     from kvq import nnops
-    seen = {"nt": 0, "nn": 0, "tn": 0, "gelu": 0, "dgelu": 0, "grouped": 0, "any": 0, "tiles": set()}
+    seen = {"nt": 0, "nn": 0, "tn": 0, "gelu": 0, "dgelu": 0, "dropres": 0, "grouped": 0, "any": 0, "tiles": set()}
     worst = [0.0, ""]
     real = dict(gemm=nnops.gemm, gemm_gelu=nnops.gemm_gelu, gemm_dgelu=nnops.gemm_dgelu, gemm_problem=nnops.gemm_problem,
-                gemm_grouped=nnops.gemm_grouped)
+                gemm_grouped=nnops.gemm_grouped, gemm_dropres=nnops.gemm_dropres)
     recorded = {}
 
     def ref(a, b, layout):                                # (the saved torch.mm: the checker may multiply with the library)
@@ -64,6 +64,16 @@ def _judged_gemms(monkeypatch, tol=4e-3):
         seen["dgelu"] += 1
         return g_h, part
 
+    def gemm_dropres(x, w, bias, resid, p_drop, seed, site, tile=None):
+        # the dense layer in front of a residual LayerNorm with dropout + residual in its epilogue (round 5); judged where the
+        # step runs without dropout (training=False), launched unjudged otherwise
+        pre = real["gemm_dropres"](x, w, bias, resid, p_drop, seed, site, tile=tile)
+        if p_drop == 0.0:
+            judge(pre, (ref(x, w, "nt") + bias.float()).to(torch.bfloat16).float() + resid.float(), f"gemm_dropres {tuple(pre.shape)} K={x.shape[1]}")
+        seen["dropres"] += 1
+        seen["tiles"].add(nnops.TILE_NAMES[nnops.pick_tile(x.shape[0], w.shape[0], x.shape[1], candidates=nnops.DROPRES_TILES)])
+        return pre
+
     def gemm_problem(a, b, out, layout, bias=None, accumulate=False):
         pr = real["gemm_problem"](a, b, out, layout, bias=bias, accumulate=accumulate)
         recorded[out.data_ptr()] = (a, b, out, layout)
@@ -77,7 +87,8 @@ def _judged_gemms(monkeypatch, tol=4e-3):
                 judge(out, ref(a, b, lay), f"grouped {lay} {tuple(out.shape)} tile={tile}")
                 seen["grouped"] += 1
 
-    for k, f in dict(gemm=gemm, gemm_gelu=gemm_gelu, gemm_dgelu=gemm_dgelu, gemm_problem=gemm_problem, gemm_grouped=gemm_grouped).items():
+    for k, f in dict(gemm=gemm, gemm_gelu=gemm_gelu, gemm_dgelu=gemm_dgelu, gemm_problem=gemm_problem, gemm_grouped=gemm_grouped,
+                     gemm_dropres=gemm_dropres).items():
         monkeypatch.setattr(nnops, k, f)
     return seen, worst, recorded
 
@@ -127,7 +138,7 @@ def test_engine_bf16_at_the_reference_batch_shapes_runs_no_vendor_gemm(B, monkey
     np.testing.assert_allclose(out["loss_recon"].item(), ref_loss, rtol=2e-2)
     print(f"B={B}: own GEMM launches inside the step:", {k: v for k, v in seen.items() if k != "tiles"}, "tiles", sorted(seen["tiles"]),
           "worst", worst)
-    assert seen["nt"] >= 12 and seen["nn"] >= 14 and seen["tn"] >= 1 and seen["grouped"] >= 20 and seen["any"] == 0
+    assert seen["nt"] >= 8 and seen["dropres"] == 10 and seen["nn"] >= 14 and seen["tn"] >= 1 and seen["grouped"] >= 20 and seen["any"] == 0
     if B <= 128:
         assert "64x128" in seen["tiles"]                       # the small tile is what these row counts run on
 

@@ -131,7 +131,7 @@ def _gelu(x):
     return torch.nn.functional.gelu(x)
 
 
-@pytest.mark.parametrize("tile", ["256x192", "128x256", "128x192h"])
+@pytest.mark.parametrize("tile", ["256x192", "128x256"])
 def test_gemm_gelu_epilogue(tile):
     """BertIntermediate (modeling_bert.py:325-337): h = x W^T + b and gelu(h) from one kernel."""
     from kvq import nnops
@@ -316,3 +316,29 @@ def test_pick_tile_rule():
     name = lambda M, N: nnops.TILE_NAMES[nnops.pick_tile(M, N)]
     assert name(8192, 768) == "128x192" and name(8192, 3072) == "256x192" and name(8192, 18432) == "256x256" and name(8192, 30528) == "256x256"
     assert name(768, 768) == "64x128" and name(1536, 768) == "64x128"
+
+
+@pytest.mark.parametrize("tile", ["128x192", "128x256", "64x128", None])
+@pytest.mark.parametrize("shape,p_drop", [((1032, 776, 256), 0.1), ((8192, 768, 768), 0.1), ((520, 768, 3072), 0.0), ((264, 200, 64), 0.5)])
+def test_gemm_dropout_residual_epilogue_equals_the_two_kernel_form(tile, shape, p_drop):
+    """kvq_gemm_bf16_dropres (round 5): the dense layer of a BertSelfOutput / BertOutput block (modeling_bert.py:282-296, 339-352)
+    with dropout and the residual add in its epilogue stores, BIT FOR BIT, the `pre` that kvq_dropout_residual_ln_fwd stores behind
+    the plain GEMM (same roundings, same Philox masks), and LayerNorm alone behind it gives the two-kernel form's output."""
+    from kvq import nnops
+    M, N, K = shape
+    a, b, _ = _ops("nt", M, N, K, seed=M + K)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    bias = torch.randn(N, generator=g, device="cuda").to(torch.bfloat16)
+    resid = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
+    gamma, beta = torch.randn(N, generator=g, device="cuda"), torch.randn(N, generator=g, device="cuda")
+    seed, site = 123456789, 7
+    y = nnops.gemm(a, b, "nt", bias=bias)
+    out0, pre0, mean0, rstd0 = nnops.ln_fwd(y, resid, gamma, beta, 1e-12, p_drop, seed, site)
+    pre1 = nnops.gemm_dropres(a, b, bias, resid, p_drop, seed, site, tile=tile)
+    assert torch.equal(pre1.view(torch.int16), pre0.view(torch.int16))
+    if p_drop > 0:                                   # the mask is there: about p_drop of the elements are the bare residual
+        dropped = (pre1 == resid).float().mean().item()
+        assert abs(dropped - p_drop) < 0.02, dropped
+    out1, none, mean1, rstd1 = nnops.ln_fwd(pre1, None, gamma, beta, 1e-12, 0.0, 0, 0, save_pre=False)
+    assert none is None and torch.equal(out1.view(torch.int16), out0.view(torch.int16))
+    assert torch.equal(mean1, mean0) and torch.equal(rstd1, rstd0)

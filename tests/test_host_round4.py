@@ -15,17 +15,11 @@ def test_pick_tile_rule_reproduces_the_measured_choices():
     """kvq.nnops.pick_tile / persistent_pays: at the benchmarked 8192 rows the rule's picks are the per-shape
     choices measured in rounds 2 - 3 (the tables it replaced); at the reference's own row counts it turns to the small tile."""
     from kvq import nnops
-    def name(M, N, K, lay="nt"):                       # nnops.gemm()'s rule with tile=None
-        if nnops.half_cu_pays(M, N, K, lay):
-            return "128x192h"
-        return nnops.TILE_NAMES[nnops.pick_tile(M, N, K)] + ("p" if nnops.persistent_pays(nnops.pick_tile(M, N, K), M, N, K, lay) else "")
-    # forward (y = x W^T): the former _OWN_FWD table, (N, K) -> tile; round 5: two to eight 128 x 192 tiles per CU and a short
-    # contraction -> the four-wave tile that runs two workgroups per CU (QKV: 34.5 us against 37.0 persistent; FFN1 39.6 against 41.6)
+    name = lambda M, N, K, lay="nt": nnops.TILE_NAMES[nnops.pick_tile(M, N, K)] + ("p" if nnops.persistent_pays(nnops.pick_tile(M, N, K), M, N, K, lay) else "")
+    # forward (y = x W^T): the former _OWN_FWD table, (N, K) -> tile
     assert [name(8192, n, k) for n, k in ((768, 768), (768, 3072), (2304, 768), (18432, 768), (30528, 768))] == \
-        ["128x192", "128x192", "128x192h", "256x256p", "256x256"]
-    assert name(8192, 3072, 768) == "128x192h"                     # (FFN1: its GELU epilogue exists for this tile too)
-    assert nnops.TILE_NAMES[nnops.pick_tile(8192, 3072, 768)] == "256x192" and not nnops.half_cu_pays(8192, 3072, 768, "nn")
-    assert not nnops.half_cu_pays(2048, 3072, 768, "nt") and not nnops.half_cu_pays(8192, 2304, 768, "nt", accumulate=True)
+        ["128x192", "128x192", "128x192p", "256x256p", "256x256"]
+    assert name(8192, 3072, 768) == "256x192"                      # (FFN1: the tile its GELU epilogue exists for)
     # input gradients (gx = gy W): the former _OWN_DGRAD table; the persistent form is NT only
     assert [name(8192, n, k, "nn") for n, k in ((768, 768), (768, 2304), (768, 3072), (3072, 768), (768, 18432), (768, 30528))] == \
         ["128x192", "128x192", "128x192", "256x192", "128x192", "128x192"]

@@ -35,7 +35,7 @@ else:
     a, b = rnd(K, M), rnd(K, N)
 out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
 bias = rnd(N)
-bm, bn = (int(v) for v in tile.split("x"))
+bm, bn = (int(v) for v in tile.rstrip("hp").split("x"))      # ("128x192h": the four-wave tile, two workgroups per CU)
 ntiles = -(-M // bm) * -(-N // bn)
 buf = torch.zeros((ntiles, 16), dtype=torch.int64, device=dev)
 trash = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
