@@ -384,7 +384,8 @@ int kvq_fp8_quantize(const void* x_bf16, int64_t rows, int cols, int64_t ld, voi
 /* Activations, one pass ("delayed scaling"): per call site a device record of kvq_fp8_state_floats() floats, [0] = scale
  * (initialise to 1), the rest per-workgroup amax partials (initialise to 0): quantise with the site's scale and leave this
  * tensor's amax in the partials; kvq_fp8_update_scales (once per step, nsites consecutive records) sets
- * scale = 448 / (amax * headroom) and clears the partials.  Values beyond the previous step's range saturate at +-448. */
+ * scale = 448 / (amax * headroom) and clears the partials (headroom 0: clears only -- after a forward whose amax must not
+ * count, e.g. an evaluation batch).  Values beyond the previous step's range saturate at +-448. */
 int kvq_fp8_state_floats(void);
 int kvq_fp8_quantize_delayed(const void* x_bf16, int64_t rows, int cols, int64_t ld, void* out_fp8, float* state, void* stream);
 int kvq_fp8_update_scales(float* state, int nsites, float headroom, void* stream);
@@ -392,6 +393,23 @@ int kvq_fp8_quantize_segments(const void* src_bf16, const int64_t* seg_off, cons
                               void* dst_fp8, float* amax, float* scale, void* stream);
 int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const float* scale_b, const void* bias, void* C, int M, int N,
                     int K, int lda, int ldb, int ldc, void* stream);
+/* Round 5 -- the fp8 copy of an activation written by the kernel that PRODUCES it, so that the fp8 GEMM reading it next needs no
+ * quantisation pass: each of these writes, beside its bf16 result, exactly the bytes kvq_fp8_quantize_delayed(result, state) would
+ * write (the site's scale of the previous step) and notes the result's amax in the state's partial slots (atomic maxima: any
+ * number of workgroups).  The caller runs kvq_fp8_update_scales once per step as before.
+ *   kvq_dropout_residual_ln_fwd_fp8 : LayerNorm output -> the QKV / cross-attention query / BertIntermediate projections
+ *   kvq_attn_fwd_fp8                : attention context (at most 32 tokens, the MFMA kernel: kvq_attn_fwd_fp8_ok) -> BertSelfOutput.dense
+ *   kvq_gemm_fp8_nt_gelu            : BertIntermediate on the fp8 matrix cores with the GELU epilogue of kvq_gemm_bf16_gelu, and
+ *                                     (Aout_fp8 != NULL) the fp8 copy of gelu(h) -> BertOutput.dense */
+int kvq_dropout_residual_ln_fwd_fp8(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
+                                    float eps, float p_drop, uint64_t seed, uint32_t site, void* out, void* pre, float* mean, float* rstd,
+                                    void* out_fp8, float* fp8_state, void* stream);
+int kvq_attn_fwd_fp8_ok(int Sq, int Sk);
+int kvq_attn_fwd_fp8(const void* q, const void* k, const void* v, const int64_t* mask, int B, int nh, int Sq, int Sk, int dh,
+                     int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed, uint32_t site,
+                     void* out, float* lse, void* out_fp8, int ld8, float* fp8_state, void* stream);
+int kvq_gemm_fp8_nt_gelu(const void* A8, const void* B8, const float* scale_a, const float* scale_b, const void* bias, void* Hout, void* Aout,
+                         void* Aout_fp8, int ld8, float* fp8_state, int M, int N, int K, int lda, int ldb, int ldc, void* stream);
 
 /* torch.optim.Adam step (models/shelgon3/main.py:91: lr, weight_decay (L2, coupled), amsgrad) on flat buffers.
  *   p, m, v [, vmax] f32; g grad_dtype (scaled by grad_scale first); shadow_bf16 (may be NULL) receives bf16(p_new).

@@ -151,6 +151,62 @@ static inline unsigned drop_threshold(float p) {
 // device-resident addend of every dropout seed (kvq_set_seed_offset, per calling thread; csrc/kvq_nn.hip)
 const unsigned long long* seed_offset_ptr();
 
+// ---- fp8 (OCP e4m3fn) quantisation of bf16 values, shared by csrc/kvq_fp8.hip (the quantisation passes) and the kernels that emit
+//      the fp8 copy of an activation while they produce it (round 5: LayerNorm forward, attention forward, the GELU epilogue)
+constexpr float FP8_MAX = 448.0f;
+
+__device__ __forceinline__ float amax8(const uint4 r) {          // (a NaN element does not enter the maximum: the scale stays usable)
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        m = fmaxf(m, fabsf(__uint_as_float(w[u] << 16)));
+        m = fmaxf(m, fabsf(__uint_as_float(w[u] & 0xffff0000u)));
+    }
+    return m;
+}
+
+// 8 bf16 -> 8 fp8 (two dwords), saturating: the values are clamped to +-448 before the conversion
+__device__ __forceinline__ uint2 quant8(const uint4 r, float s) {
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+    float f[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float a = __uint_as_float(w[u] << 16) * s, b = __uint_as_float(w[u] & 0xffff0000u) * s;
+        // fminf / fmaxf return the non-NaN operand: clamp only what is a number, e4m3fn has a NaN encoding for the rest
+        f[2 * u] = a != a ? a : fminf(fmaxf(a, -FP8_MAX), FP8_MAX);
+        f[2 * u + 1] = b != b ? b : fminf(fmaxf(b, -FP8_MAX), FP8_MAX);
+    }
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
+// 4 values (already rounded to bf16) -> 4 fp8 bytes, as quant8 does it
+__device__ __forceinline__ unsigned quant4(f32x4 v, float s) {
+    float f[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = f[u] != f[u] ? f[u] : fminf(fmaxf(f[u], -FP8_MAX), FP8_MAX);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+    return (unsigned)w;
+}
+__device__ __forceinline__ float amax4(f32x4 v) {                 // (NaN does not enter, as in amax8)
+    return fmaxf(fmaxf(fmaxf(0.f, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+constexpr int FP8_PARTS = 512;                  // partial-amax slots of a delayed-scaling site (kvq_fp8_state_floats() = 8 + FP8_PARTS)
+// this launch's contribution to a site's amax: one atomic per wave on one of the site's 512 partial slots (non-negative floats
+// order like their bit patterns; kvq_fp8_update_scales takes the maximum over the slots and clears them)
+__device__ __forceinline__ void fp8_amax_note(float m, float* state, unsigned slot) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(state + 8 + (slot & (FP8_PARTS - 1))), __float_as_uint(m));
+}
+
 // ---- wave-level reductions (64 lanes) ------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll

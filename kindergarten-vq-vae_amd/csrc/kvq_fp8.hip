@@ -13,38 +13,8 @@
 
 namespace kvq {
 
-constexpr float FP8_MAX = 448.0f;
 constexpr int Q_THREADS = 256;
-
-__device__ __forceinline__ float amax8(const uint4 r) {          // (a NaN element does not enter the maximum: the scale stays usable)
-    const unsigned w[4] = {r.x, r.y, r.z, r.w};
-    float m = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        m = fmaxf(m, fabsf(__uint_as_float(w[u] << 16)));
-        m = fmaxf(m, fabsf(__uint_as_float(w[u] & 0xffff0000u)));
-    }
-    return m;
-}
-
-// 8 bf16 -> 8 fp8 (two dwords), saturating: the values are clamped to +-448 before the conversion
-__device__ __forceinline__ uint2 quant8(const uint4 r, float s) {
-    const unsigned w[4] = {r.x, r.y, r.z, r.w};
-    float f[8];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const float a = __uint_as_float(w[u] << 16) * s, b = __uint_as_float(w[u] & 0xffff0000u) * s;
-        // fminf / fmaxf return the non-NaN operand: clamp only what is a number, e4m3fn has a NaN encoding for the rest
-        f[2 * u] = a != a ? a : fminf(fmaxf(a, -FP8_MAX), FP8_MAX);
-        f[2 * u + 1] = b != b ? b : fminf(fmaxf(b, -FP8_MAX), FP8_MAX);
-    }
-    int lo = 0, hi = 0;
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-    return make_uint2((unsigned)lo, (unsigned)hi);
-}
+// (FP8_MAX, amax8, quant8, fp8_amax_note: kvq_common.h -- the producers of csrc/kvq_nn.hip / kvq_gemm2.hip emit the same bytes)
 
 __device__ __forceinline__ void block_amax_to(float m, float* dst) {
     __shared__ float sm[Q_THREADS / WAVE];
@@ -178,7 +148,7 @@ __global__ __launch_bounds__(Q_THREADS) void fp8_update_scales_kernel(float* sta
         float t = sm[0];
 #pragma unroll
         for (int i = 1; i < Q_THREADS / WAVE; ++i) t = fmaxf(t, sm[i]);
-        if (t > 0.f) st[0] = FP8_MAX / (t * headroom);                    // a site that was not visited keeps its scale
+        if (t > 0.f && headroom > 0.f) st[0] = FP8_MAX / (t * headroom);  // a site that was not visited keeps its scale; headroom 0: only clear
     }
 }
 
@@ -214,7 +184,7 @@ int kvq_fp8_quantize_delayed(const void* x_bf16, int64_t rows, int cols, int64_t
 }
 
 int kvq_fp8_update_scales(float* state, int nsites, float headroom, void* stream) {
-    KVQ_REQUIRE(state && nsites > 0 && headroom >= 1.0f, "kvq_fp8_update_scales: bad argument");
+    KVQ_REQUIRE(state && nsites > 0 && (headroom >= 1.0f || headroom == 0.0f), "kvq_fp8_update_scales: headroom >= 1, or 0 to only clear the amax partials");
     hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((unsigned)nsites), dim3(Q_THREADS), 0, (hipStream_t)stream, state, headroom);
     return check_launch("fp8_update_scales_kernel");
 }

@@ -71,6 +71,11 @@ struct Problem {
     const unsigned long long* seed_off;
     unsigned site, thresh;
     float inv_keep;
+    // EPI_GELU, optional (round 5): the fp8 (e4m3) copy of C2 = gelu(C) for the fp8 GEMM that reads it next (BertOutput.dense), row
+    // stride ld8 bytes, quantised with the scale in st8[0]; this launch's amax goes to st8's partial slots (kvq_fp8_quantize_delayed)
+    unsigned char* C8;
+    float* st8;
+    int ld8;
 };
 
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_CE = 3, EPI_DROPRES = 4;
@@ -522,6 +527,9 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
         }
     }
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool emit8 = EPI == EPI_GELU && pr.C8 != nullptr;               // (uniform)
+    const float s8 = emit8 ? pr.st8[0] : 1.0f;
+    float am8 = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int r = rr + it * C::RPP;
@@ -591,9 +599,14 @@ __device__ __forceinline__ void epilogue(const Problem& pr, char* smem, f32x4 (&
                     const u32x4 gg = {g.x, g.y, g.z, g.w};
                     __builtin_nontemporal_store(gg, reinterpret_cast<u32x4*>(pr.C2 + off));
                 }
+                if (emit8) {
+                    am8 = fmaxf(am8, amax8(g));
+                    *reinterpret_cast<uint2*>(pr.C8 + (size_t)m * pr.ld8 + n) = quant8(g, s8);
+                }
             }
         }
     }
+    if (emit8) fp8_amax_note(am8, pr.st8, blockIdx.x);
     if (EPI == EPI_DGELU) {
         // column sums over the tile's rows: RPP partial rows through LDS (behind the bf16 tile), then one thread per column
         float* scratch = reinterpret_cast<float*>(smem + C::BM * C::CLD);
@@ -1075,7 +1088,7 @@ __device__ __forceinline__ void cluster8(f32x4 (&acc)[C::FA][C::FB], const Frags
     __builtin_amdgcn_s_setprio(0);
 }
 
-template <class C>
+template <class C, int EPI = EPI_NONE>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm2_f8_kernel(Params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1140,7 +1153,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm2_f8_kernel(Params P)
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
-    epilogue<C, EPI_NONE>(pr, smem, acc, biasv, tid, lane, wm, wn, m0, n0, ti.tm, mul);
+    epilogue<C, EPI>(pr, smem, acc, biasv, tid, lane, wm, wn, m0, n0, ti.tm, mul);
 }
 
 // ---- tile configurations ---------------------------------------------------------------------------------------------
@@ -1276,6 +1289,7 @@ static int build_params(const kvq_gemm_problem* probs, int nprob, int layout, in
         }
         d.C2 = nullptr; d.H = nullptr; d.part = nullptr; d.vlimit = 0; d.scaleA = nullptr; d.scaleB = nullptr;
         d.seed = 0; d.seed_off = nullptr; d.site = 0; d.thresh = 0; d.inv_keep = 1.0f;
+        d.C8 = nullptr; d.st8 = nullptr; d.ld8 = 0;
         t0 += d.tiles_m * d.tiles_n;
     }
     for (int i = nprob; i < g2::MAX_PROBLEMS; ++i) P.p[i] = P.p[0];
@@ -1396,6 +1410,32 @@ int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const 
     }
     hipLaunchKernelGGL((g2::gemm2_f8_kernel<Cf>), dim3((unsigned)P.ntiles), dim3(Cf::THREADS), Cf::LDS, (hipStream_t)stream, P);
     return check_launch("gemm2_f8_kernel");
+}
+
+int kvq_gemm_fp8_nt_gelu(const void* A8, const void* B8, const float* scale_a, const float* scale_b, const void* bias, void* Hout, void* Aout,
+                         void* Aout_fp8, int ld8, float* fp8_state, int M, int N, int K, int lda, int ldb, int ldc, void* stream) {
+    KVQ_REQUIRE(scale_a && scale_b, "kvq_gemm_fp8_nt_gelu: null scale pointer");
+    KVQ_REQUIRE(K > 0 && K % 128 == 0 && lda % 16 == 0 && ldb % 16 == 0, "kvq_gemm_fp8_nt_gelu: K %% 128 == 0 and lda, ldb %% 16 == 0 (fp8 elements)");
+    KVQ_REQUIRE(Aout && ((uintptr_t)Aout & 15) == 0, "kvq_gemm_fp8_nt_gelu: null / misaligned second output");
+    KVQ_REQUIRE(!Aout_fp8 || (fp8_state && ld8 >= N && ld8 % 8 == 0 && ((uintptr_t)Aout_fp8 & 7) == 0),
+                "kvq_gemm_fp8_nt_gelu: the fp8 copy needs a state, 8-byte alignment and a row stride >= N in multiples of 8");
+    kvq_gemm_problem q;
+    q.A = A8; q.B = B8; q.C = Hout; q.bias = bias; q.M = M; q.N = N; q.K = K / 2; q.lda = lda / 2; q.ldb = ldb / 2; q.ldc = ldc; q.accumulate = 0;
+    g2::Params P;
+    if (int rc = build_params(&q, 1, KVQ_GEMM_NT, KVQ_GEMM_TILE_128x256, P, "kvq_gemm_fp8_nt_gelu")) return rc;
+    for (int i = 0; i < g2::MAX_PROBLEMS; ++i) {
+        g2::Problem& d = P.p[i];
+        d.scaleA = scale_a; d.scaleB = scale_b; d.C2 = (unsigned short*)Aout; d.C8 = (unsigned char*)Aout_fp8; d.st8 = fp8_state; d.ld8 = ld8;
+    }
+    typedef g2::Cfg128x256<true, true> Cf;
+    static std::atomic<bool> attr_done{false};
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g2::gemm2_f8_kernel<Cf, g2::EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+        if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm2_f8 gelu): %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((g2::gemm2_f8_kernel<Cf, g2::EPI_GELU>), dim3((unsigned)P.ntiles), dim3(Cf::THREADS), Cf::LDS, (hipStream_t)stream, P);
+    return check_launch("gemm2_f8_kernel<gelu>");
 }
 
 int64_t kvq_gemm_dgelu_partial_rows(int64_t M, int tile) {

@@ -36,7 +36,10 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
                                                         unsigned long long seed, const unsigned long long* __restrict__ seed_off,
                                                         unsigned site, void* __restrict__ out,
                                                         void* __restrict__ pre, float* __restrict__ mean_out,
-                                                        float* __restrict__ rstd_out) {
+                                                        float* __restrict__ rstd_out, unsigned char* __restrict__ out8 = nullptr,
+                                                        float* __restrict__ st8 = nullptr) {
+    // out8 / st8 (round 5, bf16 io only): also the fp8 (e4m3) copy of `out` for the fp8 GEMM that reads it next -- the bytes
+    // kvq_fp8_quantize_delayed(out) would write (this site's scale of the previous step, this call's amax noted in its state)
     // EVERY load of the row is requested before anything is done with one of them, and no load sits behind a branch: chunk
     // indices past the row are clamped (and masked out of the sums), a missing residual reads y again and is weighted 0.
     // As first written ("if (c < nchunk) { load y; ...; if (resid) load resid; ... }" per chunk) hipcc put s_waitcnt vmcnt(0)
@@ -98,6 +101,8 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
     }
     const float var = wave_sum_f32(sq) / (float)H;
     const float rstd = rsqrtf(var + eps);
+    const float s8 = (DT == KVQ_BF16 && out8) ? st8[0] : 1.0f;
+    float am8 = 0.f;
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
         const int c = lane + WAVE * t;
@@ -107,8 +112,14 @@ __global__ __launch_bounds__(256) void drln_fwd_kernel(const void* __restrict__ 
             else { gg = *reinterpret_cast<const f32x4*>(gamma + 4 * c); bb = *reinterpret_cast<const f32x4*>(beta + 4 * c); }
             const f32x4 o = (v[t] - mean) * rstd * gg + bb;
             IO<DT>::store4(out, (size_t)row * H + 4 * c, o);
+            if (DT == KVQ_BF16 && out8) {                     // (uniform)
+                const f32x4 ob = {IO<DT>::round(o.x), IO<DT>::round(o.y), IO<DT>::round(o.z), IO<DT>::round(o.w)};
+                am8 = fmaxf(am8, amax4(ob));
+                *reinterpret_cast<unsigned*>(out8 + (size_t)row * H + 4 * c) = quant4(ob, s8);
+            }
         }
     }
+    if (DT == KVQ_BF16 && out8) fp8_amax_note(am8, st8, (unsigned)row);
     if (lane == 0) {
         if (mean_out) mean_out[row] = mean;
         if (rstd_out) rstd_out[row] = rstd;
@@ -1227,6 +1238,9 @@ struct AttnParams {
     unsigned long long seed;
     const unsigned long long* seed_off;   // optional device-resident addend of the seed (see kvq_set_seed_offset)
     unsigned site;
+    unsigned char* out8;                  // forward, optional (round 5): fp8 (e4m3) copy of `out`, row stride ld8 bytes, and the
+    float* st8;                           // delayed-scaling state of the fp8 GEMM that reads it (kvq_fp8_quantize_delayed's contract)
+    int ld8;
 };
 
 // LDS tiles hold the io dtype (bf16 tiles halve the footprint -> twice the resident waves); arithmetic is f32.
@@ -1860,7 +1874,8 @@ __device__ __forceinline__ void store_ct(void* base, size_t row_off, int h, int 
 // LDS row image and leave as eight full 128-byte lines per wave-instruction (eight lanes per row) instead of 32 bytes of each of 32
 // lines.  T must be free (4608 bytes): every earlier read of it complete (one wave per workgroup: LDS operations stay in order).
 __device__ __forceinline__ void store_rows_coalesced(unsigned* T, void* base, size_t row0_off, int ld, int S, int r, int h, int lane,
-                                                     const f32x16& c0, const f32x16& c1) {
+                                                     const f32x16& c0, const f32x16& c1, unsigned char* base8 = nullptr, size_t row0_off8 = 0,
+                                                     int ld8 = 0, float* st8 = nullptr, unsigned slot8 = 0) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     char* t = reinterpret_cast<char*>(T);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1881,12 +1896,21 @@ __device__ __forceinline__ void store_rows_coalesced(unsigned* T, void* base, si
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     unsigned short* p = reinterpret_cast<unsigned short*>(base) + row0_off + 8 * (lane & 7);
+    const float s8 = base8 ? st8[0] : 1.0f;
+    float am8 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = 8 * j + (lane >> 3);
         const uint4 v = *reinterpret_cast<const uint4*>(t + row * 144 + (lane & 7) * 16);
-        if (row < S) *reinterpret_cast<uint4*>(p + (size_t)row * ld) = v;
+        if (row < S) {
+            *reinterpret_cast<uint4*>(p + (size_t)row * ld) = v;
+            if (base8) {                                                  // (uniform) the fp8 copy of the same 8 values
+                am8 = fmaxf(am8, amax8(v));
+                *reinterpret_cast<uint2*>(base8 + row0_off8 + (size_t)row * ld8 + 8 * (lane & 7)) = quant8(v, s8);
+            }
+        }
     }
+    if (base8) fp8_amax_note(am8, st8, slot8);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
@@ -1985,7 +2009,8 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnParams p) {
         for (int st = 0; st < 2; ++st) o2[dt] = mfma32(frag_from_pairs<1>(Vt, 32 * dt + r, h, st), pf[st], o2[dt]);   // O^T[d][query]
         if (!STC && qvalid) store_ct(p.out, ((size_t)b * p.Sq + r) * p.ldo + hd * AT_D, h, 32 * dt, o2[dt]);
     }
-    if constexpr (STC) store_rows_coalesced(Vt, p.out, (size_t)b * p.Sq * p.ldo + hd * AT_D, p.ldo, p.Sq, r, h, lane, o2[0], o2[1]);
+    if constexpr (STC) store_rows_coalesced(Vt, p.out, (size_t)b * p.Sq * p.ldo + hd * AT_D, p.ldo, p.Sq, r, h, lane, o2[0], o2[1],
+                                            p.out8, (size_t)b * p.Sq * p.ld8 + hd * AT_D, p.ld8, p.st8, (unsigned)bh);
     if (qvalid && h == 0 && p.lse) p.lse[((size_t)b * p.nh + hd) * p.Sq + r] = lse;
     NN_DIAG_STORE(nn_t0, nn_t1, nn_t2)
 }
@@ -2437,9 +2462,26 @@ int kvq_nn_diag_set_buffer(void* buf) {       // diagnostic library only: [workg
 }
 #endif
 
+static int drln_fwd_impl(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
+                         float eps, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* pre,
+                         float* mean, float* rstd, unsigned char* out8, float* st8, void* stream);
+
 int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
                                 float eps, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* pre,
                                 float* mean, float* rstd, void* stream) {
+    return drln_fwd_impl(y, resid, gamma, beta, N, H, eps, p_drop, seed, site, io_dtype, out, pre, mean, rstd, nullptr, nullptr, stream);
+}
+
+int kvq_dropout_residual_ln_fwd_fp8(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
+                                    float eps, float p_drop, uint64_t seed, uint32_t site, void* out, void* pre, float* mean, float* rstd,
+                                    void* out_fp8, float* fp8_state, void* stream) {
+    KVQ_REQUIRE(out_fp8 && fp8_state && ((uintptr_t)out_fp8 & 3) == 0, "kvq_dropout_residual_ln_fwd_fp8: null / misaligned fp8 output or state");
+    return drln_fwd_impl(y, resid, gamma, beta, N, H, eps, p_drop, seed, site, KVQ_BF16, out, pre, mean, rstd, (unsigned char*)out_fp8, fp8_state, stream);
+}
+
+static int drln_fwd_impl(const void* y, const void* resid, const float* gamma, const float* beta, int64_t N, int H,
+                         float eps, float p_drop, uint64_t seed, uint32_t site, int io_dtype, void* out, void* pre,
+                         float* mean, float* rstd, unsigned char* out8, float* st8, void* stream) {
     KVQ_REQUIRE(y && gamma && beta && out && N > 0 && H > 0, "kvq_dropout_residual_ln_fwd: bad argument");
     KVQ_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAX_PER_LANE, "kvq_dropout_residual_ln_fwd: H=%d must be a multiple of 4 and <= 4096", H);
     KVQ_REQUIRE(io_dtype == KVQ_F32 || io_dtype == KVQ_BF16, "unsupported io dtype %d", io_dtype);
@@ -2449,10 +2491,10 @@ int kvq_dropout_residual_ln_fwd(const void* y, const void* resid, const float* g
     const unsigned th = drop_threshold(p_drop);
 #define LAUNCH_LN_FWD(DTV, PERV)                                                                                          \
     hipLaunchKernelGGL((drln_fwd_kernel<DTV, PERV>), grid, dim3(256), 0, st, y, resid, gamma, beta, N, H, eps, p_drop, th, \
-                       (unsigned long long)seed, g_seed_off, site, out, pre, mean, rstd)
+                       (unsigned long long)seed, g_seed_off, site, out, pre, mean, rstd, out8, st8)
     if (!resid && H <= 768 && io_dtype == KVQ_BF16) {          // LayerNorm alone (the dense layer's epilogue added the residual)
         hipLaunchKernelGGL((drln_fwd_kernel<KVQ_BF16, 3, false>), grid, dim3(256), 0, st, y, resid, gamma, beta, N, H, eps, p_drop, th,
-                           (unsigned long long)seed, g_seed_off, site, out, pre, mean, rstd);
+                           (unsigned long long)seed, g_seed_off, site, out, pre, mean, rstd, out8, st8);
     } else
     if (H <= 768) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 3), LAUNCH_LN_FWD(KVQ_BF16, 3)); }
     else if (H <= 1024) { DISPATCH_DT(io_dtype, LAUNCH_LN_FWD(KVQ_F32, 4), LAUNCH_LN_FWD(KVQ_BF16, 4)); }
@@ -2867,18 +2909,44 @@ static int attn_check(int B, int nh, int Sq, int Sk, int dh, int io_dtype) {
 }
 static bool attn_long(int Sq, int Sk) { return Sq > AT_S || Sk > AT_S; }
 
+static int attn_fwd_impl(const void* q, const void* k, const void* v, const int64_t* mask, int B, int nh, int Sq, int Sk, int dh,
+                         int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed, uint32_t site,
+                         int io_dtype, void* out, float* lse, unsigned char* out8, int ld8, float* st8, void* stream);
+
 int kvq_attn_fwd(const void* q, const void* k, const void* v, const int64_t* mask, int B, int nh, int Sq, int Sk, int dh,
                  int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed, uint32_t site,
                  int io_dtype, void* out, float* lse, void* stream) {
+    return attn_fwd_impl(q, k, v, mask, B, nh, Sq, Sk, dh, ldq, ldk, ldv, ldo, causal, scale, p_drop, seed, site, io_dtype, out, lse,
+                         nullptr, 0, nullptr, stream);
+}
+
+// 1 when kvq_attn_fwd_fp8 can run for these sizes (the MFMA kernel with whole-line stores: at most 32 tokens, default variant)
+int kvq_attn_fwd_fp8_ok(int Sq, int Sk) { return !attn_long(Sq, Sk) && g_attn_variant == 2 && attn_coalesced() && attn_store_coalesced() ? 1 : 0; }
+
+int kvq_attn_fwd_fp8(const void* q, const void* k, const void* v, const int64_t* mask, int B, int nh, int Sq, int Sk, int dh,
+                     int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed, uint32_t site,
+                     void* out, float* lse, void* out_fp8, int ld8, float* fp8_state, void* stream) {
+    KVQ_REQUIRE(out_fp8 && fp8_state && ld8 >= nh * dh && ld8 % 8 == 0 && ((uintptr_t)out_fp8 & 7) == 0,
+                "kvq_attn_fwd_fp8: fp8 output (8-byte aligned, row stride >= nh * dh, a multiple of 8) and state required");
+    KVQ_REQUIRE(kvq_attn_fwd_fp8_ok(Sq, Sk), "kvq_attn_fwd_fp8: only the 32-token MFMA kernel emits the fp8 copy (kvq_attn_fwd_fp8_ok)");
+    return attn_fwd_impl(q, k, v, mask, B, nh, Sq, Sk, dh, ldq, ldk, ldv, ldo, causal, scale, p_drop, seed, site, KVQ_BF16, out, lse,
+                         (unsigned char*)out_fp8, ld8, fp8_state, stream);
+}
+
+static int attn_fwd_impl(const void* q, const void* k, const void* v, const int64_t* mask, int B, int nh, int Sq, int Sk, int dh,
+                         int ldq, int ldk, int ldv, int ldo, int causal, float scale, float p_drop, uint64_t seed, uint32_t site,
+                         int io_dtype, void* out, float* lse, unsigned char* out8, int ld8, float* st8, void* stream) {
     KVQ_REQUIRE(q && k && v && out, "kvq_attn_fwd: null pointer argument");
     int rc = attn_check(B, nh, Sq, Sk, dh, io_dtype);
     if (rc) return rc;
     AttnParams p = {};
+    p.out8 = out8; p.ld8 = ld8; p.st8 = st8;
     p.q = q; p.k = k; p.v = v; p.out = out; p.lse = lse; p.mask = mask;
     p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.causal = causal;
     p.scale = scale; p.p_drop = p_drop; p.thresh = drop_threshold(p_drop); p.seed = seed; p.seed_off = g_seed_off; p.site = site;
     hipStream_t st = (hipStream_t)stream;
     const bool al = (ldq % 8 == 0) && (ldk % 8 == 0) && (ldv % 8 == 0) && (ldo % 8 == 0) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0);
+    KVQ_REQUIRE(!out8 || al, "kvq_attn_fwd_fp8: 16-byte aligned rows required");
     if (attn_long(Sq, Sk)) {
         KVQ_REQUIRE(al, "kvq_attn_fwd: sequences above %d tokens need 16-byte aligned rows", AT_S);
         KVQ_REQUIRE(!causal || Sq == Sk, "kvq_attn_fwd: causal attention needs Sq == Sk");

@@ -100,6 +100,11 @@ SIGNATURES = {
     "kvq_fp8_update_scales": (_int, [_vp, _int, _f32, _vp]),
     "kvq_fp8_quantize_segments": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp]),
     "kvq_gemm_fp8_nt": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
+    "kvq_dropout_residual_ln_fwd_fp8": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "kvq_attn_fwd_fp8_ok": (_int, [_int, _int]),
+    "kvq_attn_fwd_fp8": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _f32, _f32,
+                                C.c_uint64, C.c_uint32, _vp, _vp, _vp, _int, _vp, _vp]),
+    "kvq_gemm_fp8_nt_gelu": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_bf16_dropres": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _f32, C.c_uint64, C.c_uint32, _vp]),
     "kvq_gemm_bf16_gelu": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_gemm_dgelu_partial_rows": (_i64, [_i64, _int]),

@@ -538,10 +538,16 @@ class TrainEngine:
         # _FP8_MIN_ROWS wide: the LM head and the all-layer cross-K/V projection (tools/gemm2_probe_fp8_own.py, profiles/r04_fp8.md:
         # 292 against 350 us and 184 against 217; every per-layer GEMM LOSES 4 - 8 us to its quantisation pass).
         # "all" / KVQ_FP8=all: every forward GEMM (rounds 2 - 3; kept for the numerics tests and as the A/B arm).
+        # "fused" / KVQ_FP8=fused (round 5): every forward GEMM of the layers, each reading an fp8 copy of its input that the kernel
+        # PRODUCING that input wrote beside the bf16 one (LayerNorm forward, attention forward, the GELU epilogue of the fp8
+        # BertIntermediate GEMM: kvq_*_fp8) -- the 120 quantisation passes of "all" are gone; what still takes a pass is the input
+        # of a layer-0 QKV projection (embedding kernel) and of the cross-K/V projection (quantiser output).
         if fp8_forward is None:
-            fp8_forward = {"0": False, "1": True, "all": "all"}.get(os.environ.get("KVQ_FP8", "0"), False)
+            fp8_forward = {"0": False, "1": True, "all": "all", "fused": "fused"}.get(os.environ.get("KVQ_FP8", "0"), False)
         self.fp8 = bool(fp8_forward)
-        self._fp8_all = fp8_forward == "all"
+        self._fp8_fused = fp8_forward == "fused"
+        self._fp8_all = fp8_forward in ("all", "fused")
+        self._x8 = {}                      # data_ptr of a bf16 activation -> its fp8 copy, left by the producer for ONE fp8 GEMM
         if self.fp8:
             if self.dtype != torch.bfloat16:
                 raise KvqError("TrainEngine: fp8 forward GEMMs need the bf16 compute dtype")
@@ -651,11 +657,18 @@ class TrainEngine:
         self._w8_scale = torch.ones(len(keys), dtype=torch.float32, device=self.dev)
         self._fp8_quantize_weights()
         # activations: one {scale, amax} pair per GEMM input of the step, in call order (delayed scaling: include/kvq.h)
-        self._a8_sites = 8 * (self.n_enc_layers + self.n_dec_layers) + 8
+        self._a8_sites = len(keys)                    # one record per fp8 GEMM = per weight key (each is used once per forward)
         st = torch.zeros((self._a8_sites, lib().kvq_fp8_state_floats()), dtype=torch.float32, device=self.dev)
         st[:, 0] = 1.0
         self._a8_state = st
-        self._a8_site = 0
+
+    def _a8_state_of(self, key):
+        """The delayed-scaling record of the fp8 GEMM with weight `key` (its input's scale and amax partials)."""
+        return self._a8_state[self._w8_index[key]]
+
+    def _emits_fp8_for(self, key):
+        """True when the kernel that produces the input of GEMM `key` should write its fp8 copy too (scope "fused")."""
+        return self.fp8 and self._fp8_fused and key is not None and key in self._w8_index
 
     def _fp8_quantize_weights(self):
         """After every weight update: the GEMM weights of the whole model to fp8 in two launches."""
@@ -667,15 +680,20 @@ class TrainEngine:
         si = self._w8_index[key]
         o = self.flat.seg[key][0]
         W8 = self._w8[o:o + W.numel()].view(W.shape)
-        site = self._a8_site
-        self._a8_site += 1
-        if site >= self._a8_sites:
-            raise KvqError("TrainEngine: more fp8 GEMM inputs in a step than scale slots")
-        st = self._a8_state[site]
+        st = self._a8_state[si]
+        x8 = self._fp8_input(x, st, key)
+        return nnops.gemm_fp8_nt(x8, W8, st[0:], self._w8_scale[si:], bias=b)
+
+    def _fp8_input(self, x, st, key):
+        """The fp8 copy of activation x for the GEMM with weight `key` (record `st`): the one the producer of x left for exactly
+        this GEMM (scope "fused"), or a quantisation pass."""
+        x8 = self._x8.pop((x.data_ptr(), key), None)
+        if x8 is not None and tuple(x8.shape) == tuple(x.shape):
+            return x8
         x8 = torch.empty(x.shape, dtype=torch.uint8, device=self.dev)
         check(lib().kvq_fp8_quantize_delayed(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), x8.data_ptr(), st.data_ptr(), stream_ptr()),
               "kvq_fp8_quantize_delayed")
-        return nnops.gemm_fp8_nt(x8, W8, st[0:], self._w8_scale[si:], bias=b)
+        return x8
 
     def _linear(self, x, wname, bname, fused=None, Wb=None, key=None):
         if Wb is not None:
@@ -713,7 +731,7 @@ class TrainEngine:
         plain = nnops.tile_cost_us(nnops.pick_tile(M, N, K), M, N, K) + 3.0 + M * N * 4 / 3e6
         return nnops.TILE_NAMES[t] if nnops.tile_cost_us(t, M, N, K) <= plain else None
 
-    def _dense_residual_ln(self, a, wname, bname, resid, gname, betaname, eps, p_drop, site):
+    def _dense_residual_ln(self, a, wname, bname, resid, gname, betaname, eps, p_drop, site, next_key=None):
         """LayerNorm(dropout(a . W^T + b) + resid) of a BertSelfOutput / BertOutput block (modeling_bert.py:282-296, 339-352):
         (out, pre, mean, rstd) as nnops.ln_fwd returns them.  bf16 engine: the dense layer's epilogue draws the dropout mask, adds
         the residual and stores `pre` (nnops.gemm_dropres -- bit for bit the `pre` of the two-kernel form), then LayerNorm alone."""
@@ -728,12 +746,29 @@ class TrainEngine:
             out, _, mean, rstd = nnops.ln_fwd(pre, None, gamma, beta, eps, 0.0, 0, 0, save_pre=False)
             return out, pre, mean, rstd
         y = self._linear(a, wname, bname)
+        if self._emits_fp8_for(next_key):             # next_key: the GEMM that reads this block's output
+            out, pre, mean, rstd, out8 = nnops.ln_fwd_fp8(y, resid, gamma, beta, eps, p_drop, self._step_seed, site, self._a8_state_of(next_key))
+            self._x8[(out.data_ptr(), next_key)] = out8
+            return out, pre, mean, rstd
         return nnops.ln_fwd(y, resid, gamma, beta, eps, p_drop, self._step_seed, site)
 
-    def _linear_gelu(self, x, wname, bname):
+    def _linear_gelu(self, x, wname, bname, next_key=None):
         """(h, gelu(h)), h = x . W^T + b: one kernel where the own GEMM carries the activation in its epilogue."""
         W, b = self.flat.w(wname), self.flat.w(bname)
         on_fp8 = self.fp8 and wname in self._w8_index         # (fp8 "all": the fp8 GEMM has no activation epilogue)
+        if on_fp8 and self._fp8_fused and x.shape[0] >= 256 and W.shape[1] % 128 == 0 and x.is_contiguous():
+            # scope "fused": BertIntermediate on the fp8 matrix cores WITH the GELU epilogue, which also leaves the fp8 copy of
+            # gelu(h) for BertOutput.dense (next_key)
+            si = self._w8_index[wname]
+            o = self.flat.seg[wname][0]
+            W8 = self._w8[o:o + W.numel()].view(W.shape)
+            st = self._a8_state[si]
+            x8 = self._fp8_input(x, st, wname)
+            if self._emits_fp8_for(next_key):
+                h, a, a8 = nnops.gemm_fp8_nt_gelu(x8, W8, st[0:], self._w8_scale[si:], b, state_out=self._a8_state_of(next_key))
+                self._x8[(a.data_ptr(), next_key)] = a8
+                return h, a
+            return nnops.gemm_fp8_nt_gelu(x8, W8, st[0:], self._w8_scale[si:], b)
         tile = None if on_fp8 else self._epilogue_tile(x.shape[0], W.shape[0], W.shape[1])
         if tile is not None and x.is_contiguous() and nnops.gemm_mfma_ok(x, W, None, "nt", b):
             return nnops.gemm_gelu(x, W, b, tile=tile)
@@ -948,7 +983,7 @@ class TrainEngine:
             part = nnops.colsum_partial(g_pt)
             self._defer(part, gt[0], part.shape[0], Hh, Hh)
 
-    def _attn_block_fwd(self, pre, x, kv_src, mask, causal, cfg, training, B, Sq, Sk, kv_pre=None):
+    def _attn_block_fwd(self, pre, x, kv_src, mask, causal, cfg, training, B, Sq, Sk, kv_pre=None, next_key=None):
         """self-attention (kv_src is None) or cross-attention on kv_src (kv_pre: its already projected [N, 2H] keys | values,
         a column slice of the all-layer projection); returns LN(dropout(dense(ctx)) + x)."""
         fl, H, nh = self.flat, self.H, self.nh
@@ -964,9 +999,14 @@ class TrainEngine:
             kvbuf = kv_pre if kv_pre is not None else \
                 self._linear(kv_src, None, None, fused=([pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"]))
             q, k, v = qkv, kvbuf[:, :H], kvbuf[:, H:]
-        ctx, lse = nnops.attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a)
+        if self._emits_fp8_for(pre + "o.w") and q.dtype == torch.bfloat16 and nnops.attn_fwd_fp8_ok(Sq, Sk):
+            ctx, lse, ctx8 = nnops.attn_fwd_fp8(q, k, v, mask, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a,
+                                                self._a8_state_of(pre + "o.w"))
+            self._x8[(ctx.data_ptr(), pre + "o.w")] = ctx8
+        else:
+            ctx, lse = nnops.attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_attn, self._step_seed, site_a)
         out, lnpre, mean, rstd = self._dense_residual_ln(ctx, pre + "o.w", pre + "o.b", x, pre + "ln.w", pre + "ln.b", cfg.layer_norm_eps,
-                                                         p_hid, site_o)
+                                                         p_hid, site_o, next_key=next_key)
         # (lse: only the kernels above 32 tokens work from the saved log-sum-exp)
         return out, (x, kv_src, qkv, kvbuf, ctx, lnpre, mean, rstd, mask, causal, p_attn, p_hid, site_a, site_o, B, Sq, Sk,
                      lse if max(Sq, Sk) > 32 else None)
@@ -1015,13 +1055,13 @@ class TrainEngine:
                 self._linear_bwd(g_kv, kv_src, [pre + "k.w", pre + "v.w"], [pre + "k.b", pre + "v.b"], gx_accum=g_kv_src, bias_done=want_bkv)
         return g_x
 
-    def _ffn_fwd(self, pre, x, cfg, training):
+    def _ffn_fwd(self, pre, x, cfg, training, next_key=None):
         fl = self.flat
         p_hid = cfg.hidden_dropout_prob if training else 0.0
         site = self._site()
-        h, a = self._linear_gelu(x, pre + "f1.w", pre + "f1.b")
+        h, a = self._linear_gelu(x, pre + "f1.w", pre + "f1.b", next_key=pre + "f2.w")
         out, lnpre, mean, rstd = self._dense_residual_ln(a, pre + "f2.w", pre + "f2.b", x, pre + "ln2.w", pre + "ln2.b", cfg.layer_norm_eps,
-                                                         p_hid, site)
+                                                         p_hid, site, next_key=next_key)
         return out, (x, h, a, lnpre, mean, rstd, p_hid, site)
 
     def _ffn_bwd(self, pre, g_out, saved):
@@ -1183,7 +1223,7 @@ class TrainEngine:
             self._q_training = training if quantizer_training is None else bool(quantizer_training)
             with torch.no_grad():            # the schedule IS the backward pass: no autograd graph over the few torch ops in it
                 if self.fp8:
-                    self._a8_site = 0
+                    self._x8.clear()
                 out = self._forward_backward(input_ids, attention_mask, training, compute_grads, dec_ids, dec_mask, want_logits,
                                              defer=bool(defer_backward), target_ids=target_ids)
                 if defer_backward:
@@ -1194,6 +1234,9 @@ class TrainEngine:
                     # (evaluation, Shelgon.forward) uses the scales as they are and leaves them alone: an eval batch must not
                     # move the scales of the training step that follows it
                     check(lib().kvq_fp8_update_scales(self._a8_state.data_ptr(), self._a8_sites, 4.0, stream_ptr()), "kvq_fp8_update_scales")
+                elif self.fp8:
+                    # (the producers note amax by atomic maxima: what an evaluation batch left in the partial slots must go)
+                    check(lib().kvq_fp8_update_scales(self._a8_state.data_ptr(), self._a8_sites, 0.0, stream_ptr()), "kvq_fp8_update_scales")
                 return out
         finally:
             nnops.set_seed_offset(None)
@@ -1288,8 +1331,8 @@ class TrainEngine:
         x, emb_saved = self._emb_fwd("enc.emb.", ecfg, input_ids, training)
         enc_saved = []
         for i in range(self.n_enc_layers):
-            x, sa = self._attn_block_fwd(f"enc.{i}.sa.", x, None, mask, False, ecfg, training, B, S, S)
-            x, ff = self._ffn_fwd(f"enc.{i}.", x, ecfg, training)
+            x, sa = self._attn_block_fwd(f"enc.{i}.sa.", x, None, mask, False, ecfg, training, B, S, S, next_key=f"enc.{i}.f1.w")
+            x, ff = self._ffn_fwd(f"enc.{i}.", x, ecfg, training, next_key=f"enc.{i + 1}.sa.q.w" if i + 1 < self.n_enc_layers else None)
             enc_saved.append((sa, ff))
         z = x
         gum_saved = None
@@ -1320,13 +1363,20 @@ class TrainEngine:
             kv_all = self._linear(enc_out, None, None, Wb=(fl.fused(self._cakv_w, fl.shadow), fl.fused(self._cakv_b, fl.shadow)),
                                   key=self._cakv_w[0])
         for i in range(self.n_dec_layers):
-            y, sa = self._attn_block_fwd(f"dec.{i}.sa.", y, None, d_mask, True, dcfg, training, B, Sd, Sd)
+            y, sa = self._attn_block_fwd(f"dec.{i}.sa.", y, None, d_mask, True, dcfg, training, B, Sd, Sd, next_key=f"dec.{i}.ca.q.w")
             y, ca = self._attn_block_fwd(f"dec.{i}.ca.", y, enc_out, None, False, dcfg, training, B, Sd, S,
-                                         kv_pre=kv_all[:, 2 * H * i: 2 * H * (i + 1)] if kv_all is not None else None)
-            y, ff = self._ffn_fwd(f"dec.{i}.", y, dcfg, training)
+                                         kv_pre=kv_all[:, 2 * H * i: 2 * H * (i + 1)] if kv_all is not None else None,
+                                         next_key=f"dec.{i}.f1.w")
+            y, ff = self._ffn_fwd(f"dec.{i}.", y, dcfg, training, next_key=f"dec.{i + 1}.sa.q.w" if i + 1 < self.n_dec_layers else "head.t.w")
             dec_saved.append((sa, ca, ff))
         t, ta = self._linear_gelu(y, "head.t.w", "head.t.b")
-        hN, hpre, hmean, hrstd = nnops.ln_fwd(ta, None, fl.w32("head.ln.w"), fl.w32("head.ln.b"), dcfg.layer_norm_eps)
+        if self.fp8 and "dec.emb.word" in self._w8_index and ta.dtype == torch.bfloat16 and os.environ.get("KVQ_FP8_HEAD_EMIT", "1") != "0":
+            # the LM head runs on fp8 in every fp8 scope: the LayerNorm in front of it writes the fp8 copy of its output itself
+            hN, hpre, hmean, hrstd, hN8 = nnops.ln_fwd_fp8(ta, None, fl.w32("head.ln.w"), fl.w32("head.ln.b"), dcfg.layer_norm_eps, 0.0, 0, 0,
+                                                           self._a8_state_of("dec.emb.word"))
+            self._x8[(hN.data_ptr(), "dec.emb.word")] = hN8
+        else:
+            hN, hpre, hmean, hrstd = nnops.ln_fwd(ta, None, fl.w32("head.ln.w"), fl.w32("head.ln.b"), dcfg.layer_norm_eps)
         Wv = fl.w("dec.emb.word", rows=self.Vp)                              # [Vp,H], rows >= V are zero
         bv = fl.shadow[fl.seg["head.bias"][0]: fl.seg["head.bias"][0] + self.Vp]
         tgt = (d_ids if target_ids is None else target_ids).reshape(-1)

@@ -26,6 +26,24 @@ def ln_fwd(y, resid, gamma, beta, eps, p_drop=0.0, seed=0, site=0, save_pre=True
     return out, pre, mean, rstd
 
 
+def ln_fwd_fp8(y, resid, gamma, beta, eps, p_drop, seed, site, state, save_pre=True):
+    """ln_fwd plus the fp8 (e4m3) copy of `out` for the fp8 GEMM that reads it next: (out, pre, mean, rstd, out8).  out8 holds the
+    bytes kvq_fp8_quantize_delayed(out, state) would write; the call's amax is noted in `state` (one delayed-scaling record)."""
+    require_gpu(y, gamma, beta)
+    N, H = y.shape
+    assert y.dtype == torch.bfloat16
+    out = torch.empty_like(y)
+    out8 = torch.empty((N, H), dtype=torch.uint8, device=y.device)
+    pre = torch.empty_like(y) if save_pre else None
+    mean = torch.empty(N, dtype=torch.float32, device=y.device)
+    rstd = torch.empty(N, dtype=torch.float32, device=y.device)
+    check(lib().kvq_dropout_residual_ln_fwd_fp8(y.data_ptr(), _p(resid), gamma.data_ptr(), beta.data_ptr(), N, H, float(eps),
+                                                float(p_drop), int(seed), int(site), out.data_ptr(), _p(pre), mean.data_ptr(),
+                                                rstd.data_ptr(), out8.data_ptr(), state.data_ptr(), stream_ptr()),
+          "kvq_dropout_residual_ln_fwd_fp8")
+    return out, pre, mean, rstd, out8
+
+
 def ln_bwd(g_out, pre, mean, rstd, gamma, p_drop=0.0, seed=0, site=0, g_gamma=None, g_beta=None, accumulate=False,
            need_g_y=True, need_g_resid=True, g_bias_prev=None):
     """Returns (g_y, g_resid).  g_gamma / g_beta (f32 or bf16 [H]) are written (or accumulated into) when given;
@@ -169,6 +187,25 @@ def attn_fwd(q, k, v, mask, B, nh, Sq, Sk, causal, p_drop=0.0, seed=0, site=0, o
                              v.stride(0), ctx.stride(0), int(causal), 1.0 / 8.0, float(p_drop), int(seed), int(site),
                              io_dtype_of(q), ctx.data_ptr(), lse.data_ptr(), stream_ptr()), "kvq_attn_fwd")
     return ctx, lse
+
+
+def attn_fwd_fp8_ok(Sq, Sk):
+    return bool(lib().kvq_attn_fwd_fp8_ok(int(Sq), int(Sk)))
+
+
+def attn_fwd_fp8(q, k, v, mask, B, nh, Sq, Sk, causal, p_drop, seed, site, state):
+    """attn_fwd plus the fp8 copy of the context for the fp8 BertSelfOutput.dense: (ctx, lse, ctx8) -- see ln_fwd_fp8."""
+    require_gpu(q, k, v)
+    dh = 64
+    assert q.dtype == torch.bfloat16
+    ctx = torch.empty((B * Sq, nh * dh), dtype=q.dtype, device=q.device)
+    ctx8 = torch.empty((B * Sq, nh * dh), dtype=torch.uint8, device=q.device)
+    lse = torch.empty((B, nh, Sq), dtype=torch.float32, device=q.device)
+    check(lib().kvq_attn_fwd_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(mask), B, nh, Sq, Sk, dh, q.stride(0), k.stride(0),
+                                 v.stride(0), ctx.stride(0), int(causal), 1.0 / 8.0, float(p_drop), int(seed), int(site),
+                                 ctx.data_ptr(), lse.data_ptr(), ctx8.data_ptr(), ctx8.stride(0), state.data_ptr(), stream_ptr()),
+          "kvq_attn_fwd_fp8")
+    return ctx, lse, ctx8
 
 
 def attn_bwd(q, k, v, mask, g_ctx, B, nh, Sq, Sk, causal, p_drop, seed, site, g_q, g_k, g_v, bias_part_q=None, bias_part_k=None,
@@ -547,6 +584,20 @@ def gemm_fp8_nt(a8, b8, scale_a, scale_b, bias=None, out=None):
     check(lib().kvq_gemm_fp8_nt(a8.data_ptr(), b8.data_ptr(), scale_a.data_ptr(), scale_b.data_ptr(), _p(bias), out.data_ptr(), M, N, K,
                                 a8.stride(0), b8.stride(0), out.stride(0), stream_ptr()), "kvq_gemm_fp8_nt")
     return out
+
+
+def gemm_fp8_nt_gelu(a8, b8, scale_a, scale_b, bias, state_out=None):
+    """(h, gelu(h)[, fp8 copy of gelu(h)]) with h = (a8 @ b8.T) / (scale_a * scale_b) + bias on the fp8 matrix cores: BertIntermediate
+    with the GELU epilogue of gemm_gelu; state_out = the delayed-scaling record of the fp8 GEMM that reads gelu(h) next."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    h = torch.empty((M, N), dtype=torch.bfloat16, device=a8.device)
+    a = torch.empty_like(h)
+    a_8 = torch.empty((M, N), dtype=torch.uint8, device=a8.device) if state_out is not None else None
+    check(lib().kvq_gemm_fp8_nt_gelu(a8.data_ptr(), b8.data_ptr(), scale_a.data_ptr(), scale_b.data_ptr(), _p(bias), h.data_ptr(),
+                                     a.data_ptr(), _p(a_8), N if a_8 is not None else 0, _p(state_out), M, N, K, a8.stride(0), b8.stride(0),
+                                     h.stride(0), stream_ptr()), "kvq_gemm_fp8_nt_gelu")
+    return (h, a, a_8) if a_8 is not None else (h, a)
 
 
 # ---- clock probe (bench.py) -----------------------------------------------------------------------------------------------------

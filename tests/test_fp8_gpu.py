@@ -60,7 +60,7 @@ def _build(seed=0):
     return Shelgon("kvq-bert-base-2l", vq, "kvq-bert-base-2l", None, compute_dtype=torch.bfloat16).cuda().eval()
 
 
-@pytest.mark.parametrize("scope", ["all", True])
+@pytest.mark.parametrize("scope", ["all", "fused", True])
 def test_engine_fp8_forward_against_the_bf16_engine(scope):
     """bert-base widths, 2 layers, 2048 tokens: forward GEMMs on the fp8 matrix cores -- every one ("all") or, the default of
     fp8_forward=True, the two that pay for their quantisation pass (LM head, all-layer cross-K/V) --, backward in bf16.
@@ -84,9 +84,9 @@ def test_engine_fp8_forward_against_the_bf16_engine(scope):
     assert min(cos) > 0.9 and np.mean(cos) > 0.98, (min(cos), np.mean(cos))
     # the weight mirror: every segment is the torch conversion of the bf16 shadow at that segment's own scale
     # (two decoder layers: the all-layer cross-K/V block is 3072 rows, below the width from which fp8 pays; at 12 layers it is 18432)
-    assert ("enc.0.f1.w" in e8._w8_index) == (scope == "all") and "dec.emb.word" in e8._w8_index
-    assert (e8._cakv_w[0] in e8._w8_index) == (scope == "all")
-    key = "enc.0.f1.w" if scope == "all" else "dec.emb.word"
+    assert ("enc.0.f1.w" in e8._w8_index) == (scope in ("all", "fused")) and "dec.emb.word" in e8._w8_index
+    assert (e8._cakv_w[0] in e8._w8_index) == (scope in ("all", "fused"))
+    key = "enc.0.f1.w" if scope in ("all", "fused") else "dec.emb.word"
     si, (o, n, shape) = e8._w8_index[key], e8.flat.seg[key]
     n = e8._w8_n[si].item()
     want, s = _ref_quant(e8.flat.shadow[o:o + n])
@@ -175,3 +175,114 @@ def test_weight_quantisation_replayed_from_a_graph_equals_eager():
         quantise()                                                                   # eager, same stream: the truth
         assert torch.equal(scale, got_scale), f"replay {it}: {(scale != got_scale).sum().item()} of {nseg} scales differ from the eager call"
         assert torch.equal(dst, got), f"replay {it}: quantised bytes differ"
+
+
+# ---- round 5: the fp8 copy of an activation written by the kernel that produces it ---------------------------------------------------
+def _state(scale):
+    from kvq._ffi import lib
+    st = torch.zeros(lib().kvq_fp8_state_floats(), dtype=torch.float32, device="cuda")
+    st[0] = scale
+    return st
+
+
+def _pass(x, scale):
+    """kvq_fp8_quantize_delayed(x) with the given scale: (bytes, the scale kvq_fp8_update_scales derives from its amax)."""
+    from kvq._ffi import check, lib
+    from kvq.functional import _workspace  # noqa: F401  (loads the library)
+    st = _state(scale)
+    x8 = torch.empty(x.shape, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    check(lib().kvq_fp8_quantize_delayed(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), x8.data_ptr(), st.data_ptr(), s), "q")
+    check(lib().kvq_fp8_update_scales(st.data_ptr(), 1, 4.0, s), "u")
+    return x8, st[0].item()
+
+
+def _next_scale(st):
+    from kvq._ffi import check, lib
+    check(lib().kvq_fp8_update_scales(st.data_ptr(), 1, 4.0, torch.cuda.current_stream().cuda_stream), "u")
+    assert float(st[8:].abs().max()) == 0.0                     # partials cleared
+    return st[0].item()
+
+
+@pytest.mark.parametrize("N,H,resid,p_drop", [(8192, 768, True, 0.1), (520, 768, False, 0.0), (64, 128, True, 0.0)])
+def test_layernorm_forward_writes_the_bytes_of_the_quantisation_pass(N, H, resid, p_drop):
+    from kvq import nnops
+    g = torch.Generator(device="cuda").manual_seed(N)
+    y = torch.randn((N, H), generator=g, device="cuda").to(torch.bfloat16)
+    r = torch.randn((N, H), generator=g, device="cuda").to(torch.bfloat16) if resid else None
+    gamma, beta = torch.randn(H, generator=g, device="cuda"), torch.randn(H, generator=g, device="cuda")
+    st = _state(37.5)
+    out, pre, mean, rstd, out8 = nnops.ln_fwd_fp8(y, r, gamma, beta, 1e-12, p_drop, 99, 3, st)
+    out0, pre0, mean0, rstd0 = nnops.ln_fwd(y, r, gamma, beta, 1e-12, p_drop, 99, 3)
+    assert torch.equal(out.view(torch.int16), out0.view(torch.int16)) and torch.equal(pre.view(torch.int16), pre0.view(torch.int16))
+    assert torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+    want8, want_scale = _pass(out0, 37.5)
+    assert torch.equal(out8, want8)
+    assert _next_scale(st) == want_scale
+    # ... and what it means: the torch conversion of out * scale
+    ref = (out0.float() * 37.5).clamp(-448, 448).cpu().to(torch.float8_e4m3fn).float()
+    assert torch.equal(out8.cpu().view(torch.float8_e4m3fn).float(), ref)
+
+
+@pytest.mark.parametrize("B,S,causal,p_drop", [(256, 32, False, 0.1), (16, 12, True, 0.0), (5, 32, True, 0.1)])
+def test_attention_forward_writes_the_bytes_of_the_quantisation_pass(B, S, causal, p_drop):
+    from kvq import nnops
+    nh, H = 12, 768
+    g = torch.Generator(device="cuda").manual_seed(B + S)
+    qkv = torch.randn((B * S, 3 * H), generator=g, device="cuda").to(torch.bfloat16)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    mask = (torch.rand((B, S), generator=g, device="cuda") < 0.8).long()
+    mask[:, 0] = 1
+    assert nnops.attn_fwd_fp8_ok(S, S)
+    st = _state(90.0)
+    ctx, lse, ctx8 = nnops.attn_fwd_fp8(q, k, v, mask, B, nh, S, S, causal, p_drop, 5, 11, st)
+    ctx0, lse0 = nnops.attn_fwd(q, k, v, mask, B, nh, S, S, causal, p_drop, 5, 11)
+    assert torch.equal(ctx.view(torch.int16), ctx0.view(torch.int16)) and torch.equal(lse, lse0)
+    want8, want_scale = _pass(ctx0, 90.0)
+    assert torch.equal(ctx8, want8) and _next_scale(st) == want_scale
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (520, 776, 256), (256, 256, 128)])
+def test_fp8_gemm_with_the_gelu_epilogue_and_the_fp8_copy_of_its_activation(M, N, K):
+    from kvq import nnops
+    from kvq._ffi import check, lib
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device="cuda").to(torch.bfloat16)
+    amax, sx, sw = (torch.zeros(1, device="cuda") for _ in range(3))
+    x8, w8 = torch.empty(x.shape, dtype=torch.uint8, device="cuda"), torch.empty(w.shape, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    check(lib().kvq_fp8_quantize(x.data_ptr(), M, K, K, x8.data_ptr(), amax.data_ptr(), sx.data_ptr(), s), "qx")
+    check(lib().kvq_fp8_quantize(w.data_ptr(), N, K, K, w8.data_ptr(), amax.data_ptr(), sw.data_ptr(), s), "qw")
+    h0 = nnops.gemm_fp8_nt(x8, w8, sx, sw, bias=bias)
+    st = _state(12.0)
+    h, a, a8 = nnops.gemm_fp8_nt_gelu(x8, w8, sx, sw, bias, state_out=st)
+    assert torch.equal(h.view(torch.int16), h0.view(torch.int16))                         # the same GEMM, the same rounding
+    want_a = F.gelu(h0.float())
+    assert (a.float() - want_a).abs().max().item() <= 2.0 ** -8 * want_a.abs().max().item() + 1e-3
+    want8, want_scale = _pass(a, 12.0)                                                    # the copy is the pass over what was stored
+    assert torch.equal(a8, want8) and _next_scale(st) == want_scale
+    h2, a2 = nnops.gemm_fp8_nt_gelu(x8, w8, sx, sw, bias)                                 # without the copy
+    assert torch.equal(a2.view(torch.int16), a.view(torch.int16))
+
+
+def test_fused_scope_equals_the_scope_with_quantisation_passes():
+    """Scope "fused" changes WHO writes the fp8 copies, not the bytes: three training steps (eager, capture, replay) give the
+    same losses as scope "all" up to the one kernel that differs -- BertIntermediate's GELU runs in the fp8 GEMM's epilogue
+    instead of a separate kernel (same formula, same input bits) -- and the step launches no quantisation pass for the layers."""
+    from dsentences.synthetic import random_token_batch
+    from kvq.engine import TrainEngine
+    ids, mask = (t.cuda() for t in random_token_batch(64, 32, torch.Generator().manual_seed(6)))
+    runs = {}
+    for scope in ("all", "fused"):
+        eng = TrainEngine(_build(1).train(), lr=2e-4, fp8_forward=scope)
+        losses = [float(eng.train_step(ids, mask)["loss_recon"]) for _ in range(4)]
+        runs[scope] = (losses, eng)
+    (la, ea), (lf, ef) = runs["all"], runs["fused"]
+    assert np.isfinite(lf).all() and lf[-1] < lf[0]
+    np.testing.assert_allclose(lf, la, rtol=2e-3)
+    # the activation scales the two engines arrived at (one record per GEMM weight): equal wherever the producer wrote the copy
+    sa, sf = ea._a8_state[:, 0].cpu().numpy(), ef._a8_state[:, 0].cpu().numpy()
+    assert ea._w8_index == ef._w8_index
+    np.testing.assert_allclose(sf, sa, rtol=5e-2)
