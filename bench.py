@@ -55,8 +55,9 @@ def parse():
     ap.add_argument("--bucket-mib", type=int, default=64)
     ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4]: forward GEMMs on the fp8 matrix cores where that beats the "
                     "bf16 kernel -- the LM head and the all-layer cross-K/V projection (backward bf16)")
-    ap.add_argument("--fp8-fused", action="store_true", help="round 5: every forward GEMM of the layers on fp8, reading the fp8 copy that the producer "
-                    "of its input (LayerNorm, attention, GELU epilogue) wrote beside the bf16 one: no quantisation passes")
+    ap.add_argument("--no-distance-phase", action="store_true", help="skip the 9 extra steps with the three-kernel quantiser forward that time "
+                    "the distance / arg-min kernel alone (roofline.distance_phase); kernel traces of the step use this")
+    ap.add_argument("--fp8-wide", action="store_true", help="round 4's scope: fp8 for the LM head and the all-layer cross-K/V projection only")
     ap.add_argument("--fp8-all", action="store_true", help="every forward GEMM on fp8 (rounds 2 - 3; slower: the per-layer GEMMs lose to their quantisation passes)")
     ap.add_argument("--factors", type=int, default=1, help="configs[4]: codebooks (MultiVectorQuantizer, K codes each); 1 = the reference's VectorQuantizer")
     ap.add_argument("--bagon", action="store_true", help="the plain Bagon step (models/bagon/main.py: no quantiser) with the decoder's ids "
@@ -135,7 +136,7 @@ def main():
     if a.path == "engine":
         from kvq.engine import TrainEngine
         engine = TrainEngine(model, lr=1e-4, weight_decay=0.0, amsgrad=False, milestones=[10000, 20000], gamma=0.1,
-                             bucket_mib=a.bucket_mib, fp8_forward="fused" if a.fp8_fused else ("all" if a.fp8_all else a.fp8))
+                             bucket_mib=a.bucket_mib, fp8_forward="wide" if a.fp8_wide else ("all" if a.fp8_all else a.fp8))
     else:
         params = [p for p in model.parameters() if p.requires_grad]
         opt = torch.optim.Adam(params, lr=1e-4, weight_decay=0.0, amsgrad=False, fused=True)
@@ -242,7 +243,7 @@ def main():
     # (kvq_vq_set_variant(0): the quantiser forward is an eager interlude between the step's graphs, so nothing is re-captured);
     # the event pair then brackets the distance kernel only -- same code, same operands, same place in the step
     dist_phase_ms = None
-    if engine is not None and vq is not None and not grouped and os.environ.get("KVQ_VQ_FUSED", "1") != "0" and n_ev:
+    if engine is not None and vq is not None and not grouped and os.environ.get("KVQ_VQ_FUSED", "1") != "0" and n_ev and not a.no_distance_phase:
         lib.kvq_vq_set_variant(0)
         one_step(a.warmup + a.steps)
         torch.cuda.synchronize()
@@ -334,13 +335,14 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp8 forward GEMMs / bf16" if (a.fp8 or a.fp8_all or a.fp8_fused) else "bf16") if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "dtype": ("fp8 forward GEMMs / bf16" if (a.fp8 or a.fp8_all or a.fp8_wide) else "bf16") if dtype == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": (f"Bagon (no quantiser, models/bagon/main.py) {a.model} enc/dec, decoder ids perturbed 15 % independently "
                                     f"of the encoder's, " if a.bagon else
                                     f"Bagon VQ (Shelgon) {a.model} enc/dec, {str(a.factors) + ' x ' if a.factors > 1 else ''}K={a.codes} D={D} ")
                                    + f"seq_len={a.seq_len} batch={a.batch}/GPU, mode={a.mode}, Adam, dropout on, path={a.path}"
-                                   + (", fp8 forward GEMMs (all, inputs quantised by their producers)" if a.fp8_fused else
-                                      ", fp8 forward GEMMs (all)" if a.fp8_all else ", fp8 forward GEMMs (LM head + cross-K/V)" if a.fp8 else ""),
+                                   + (", fp8 forward GEMMs (LM head + cross-K/V)" if a.fp8_wide else
+                                      ", fp8 forward GEMMs (all, behind quantisation passes)" if a.fp8_all else
+                                      ", fp8 forward GEMMs (all, inputs quantised by their producers)" if a.fp8 else ""),
                        "global_batch": world * a.batch, "seq_len": a.seq_len, "parallelism": f"dp{world}"},
             "final_loss": final_loss,
             # ids + mask + the ids' stable order (what the word-embedding gradient is summed in) are built with the batch, before the

@@ -391,6 +391,12 @@ int kvq_fp8_quantize_delayed(const void* x_bf16, int64_t rows, int cols, int64_t
 int kvq_fp8_update_scales(float* state, int nsites, float headroom, void* stream);
 int kvq_fp8_quantize_segments(const void* src_bf16, const int64_t* seg_off, const int64_t* seg_n, int nseg, int64_t max_seg_n,
                               void* dst_fp8, float* amax, float* scale, void* stream);
+/* The same inside a training step: the per-segment amax (and with it the scale) is refreshed only when the DEVICE-resident step
+ * count *step_count_u64 is a multiple of `period`; on the steps between, the segments are quantised with the scale they have
+ * (values that outgrew it saturate at +-448).  Weights move by ~lr per step: a period of 16 saves one of the two passes over the
+ * weights on 15 steps of 16. */
+int kvq_fp8_quantize_segments_periodic(const void* src_bf16, const int64_t* seg_off, const int64_t* seg_n, int nseg, int64_t max_seg_n,
+                                       void* dst_fp8, float* amax, float* scale, const void* step_count_u64, int period, void* stream);
 int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const float* scale_b, const void* bias, void* C, int M, int N,
                     int K, int lda, int ldb, int ldc, void* stream);
 /* Round 5 -- the fp8 copy of an activation written by the kernel that PRODUCES it, so that the fp8 GEMM reading it next needs no

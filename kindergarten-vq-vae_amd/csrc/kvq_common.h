@@ -198,9 +198,11 @@ __device__ __forceinline__ unsigned quant4(f32x4 v, float s) {
 __device__ __forceinline__ float amax4(f32x4 v) {                 // (NaN does not enter, as in amax8)
     return fmaxf(fmaxf(fmaxf(0.f, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
-constexpr int FP8_PARTS = 512;                  // partial-amax slots of a delayed-scaling site (kvq_fp8_state_floats() = 8 + FP8_PARTS)
-// this launch's contribution to a site's amax: one atomic per wave on one of the site's 512 partial slots (non-negative floats
-// order like their bit patterns; kvq_fp8_update_scales takes the maximum over the slots and clears them)
+constexpr int FP8_PARTS = 4096;                 // partial-amax slots of a delayed-scaling site (kvq_fp8_state_floats() = 8 + FP8_PARTS)
+// this launch's contribution to a site's amax: one atomic per wave on one of the site's 4096 partial slots (non-negative floats
+// order like their bit patterns; kvq_fp8_update_scales takes the maximum over the slots and clears them).  4096 slots = 128 cache
+// lines: the 8192 waves of a LayerNorm launch put 2 atomics on a word and 64 on a line -- with 512 slots (16 lines) the atomics of
+// a launch queued behind each other in L2 for microseconds
 __device__ __forceinline__ void fp8_amax_note(float m, float* state, unsigned slot) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));

@@ -36,13 +36,20 @@ __device__ __forceinline__ float scale_of(float amax) { return amax > 0.f ? FP8_
 // was the one thing in the replayed fp8 step that did not keep its place in the stream's order -- with 123 segments two identically
 // seeded runs parted ways after 8 - 14 steps (an amax cleared after the first maxima had landed), eager launches never did
 // (tools/fp8_flake.py, profiles/r04_fp8.md)
-__global__ __launch_bounds__(256) void fp8_zero_kernel(float* __restrict__ p, int n) {
+// `step` / `period` (weights inside the training step, kvq_fp8_quantize_segments_periodic): the amax accumulators are refreshed only
+// on steps that are multiples of `period` -- the step count is read on the DEVICE, so a replayed graph takes the same decision as
+// an eager step
+__global__ __launch_bounds__(256) void fp8_zero_kernel(float* __restrict__ p, int n, const unsigned long long* __restrict__ step = nullptr,
+                                                       int period = 1) {
+    if (step && period > 1 && (*step % (unsigned long long)period) != 0) return;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0.f;
 }
 
 // segments: seg s covers elements [off[s], off[s] + n[s]) of src (bf16) / dst (fp8), n[s] % 8 == 0, off[s] % 8 == 0
 __global__ __launch_bounds__(Q_THREADS) void fp8_seg_amax_kernel(const unsigned short* __restrict__ src, const int64_t* __restrict__ off,
-                                                                  const int64_t* __restrict__ n, float* __restrict__ amax) {
+                                                                  const int64_t* __restrict__ n, float* __restrict__ amax,
+                                                                  const unsigned long long* __restrict__ step = nullptr, int period = 1) {
+    if (step && period > 1 && (*step % (unsigned long long)period) != 0) return;      // (uniform over the grid)
     const int s = blockIdx.y;
     const int64_t chunks = n[s] >> 3;
     const uint4* p = reinterpret_cast<const uint4*>(src + off[s]);
@@ -94,8 +101,8 @@ __global__ __launch_bounds__(Q_THREADS) void fp8_quant_kernel(const unsigned sho
 // kvq_fp8_update_scales leaves `headroom` (4x) between the last amax and 448, which costs an fp format no precision, only
 // underflow range.  state (per site) = {scale, unused x 7, partial amax of each of the Q_PARTS workgroups}: plain stores, no
 // atomics (a thousand atomicMax on one word serialise at ~12 ns each: measured 28 us per call for a 4-us copy).
-constexpr int Q_PARTS = 512;
-constexpr int Q_STATE = 8 + Q_PARTS;            // floats per site
+constexpr int Q_PARTS = 512;                    // workgroups of the quantisation pass: it writes slots 0 .. 511
+constexpr int Q_STATE = 8 + FP8_PARTS;          // floats per site (the producers of round 5 spread their atomic maxima over 4096 slots)
 
 __global__ __launch_bounds__(Q_THREADS) void fp8_quant_delayed_kernel(const unsigned short* __restrict__ src, int64_t rows, int cols, int64_t ld,
                                                                        unsigned char* __restrict__ dst, float* __restrict__ state) {
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(Q_THREADS) void fp8_update_scales_kernel(float* sta
     __shared__ float sm[Q_THREADS / WAVE];
     float* st = state + (size_t)blockIdx.x * Q_STATE;
     float m = 0.f;
-    for (int i = threadIdx.x; i < Q_PARTS; i += Q_THREADS) {
+    for (int i = threadIdx.x; i < FP8_PARTS; i += Q_THREADS) {
         m = fmaxf(m, st[8 + i]);
         st[8 + i] = 0.f;
     }
@@ -189,16 +196,32 @@ int kvq_fp8_update_scales(float* state, int nsites, float headroom, void* stream
     return check_launch("fp8_update_scales_kernel");
 }
 
+static int quantize_segments_impl(const void* src_bf16, const int64_t* seg_off, const int64_t* seg_n, int nseg, int64_t max_seg_n, void* dst_fp8,
+                                  float* amax, float* scale, const unsigned long long* step, int period, void* stream);
+
 int kvq_fp8_quantize_segments(const void* src_bf16, const int64_t* seg_off, const int64_t* seg_n, int nseg, int64_t max_seg_n, void* dst_fp8,
                               float* amax, float* scale, void* stream) {
+    return quantize_segments_impl(src_bf16, seg_off, seg_n, nseg, max_seg_n, dst_fp8, amax, scale, nullptr, 1, stream);
+}
+
+int kvq_fp8_quantize_segments_periodic(const void* src_bf16, const int64_t* seg_off, const int64_t* seg_n, int nseg, int64_t max_seg_n,
+                                       void* dst_fp8, float* amax, float* scale, const void* step_count_u64, int period, void* stream) {
+    KVQ_REQUIRE(step_count_u64 && period >= 1, "kvq_fp8_quantize_segments_periodic: a device step counter and period >= 1");
+    return quantize_segments_impl(src_bf16, seg_off, seg_n, nseg, max_seg_n, dst_fp8, amax, scale, (const unsigned long long*)step_count_u64,
+                                  period, stream);
+}
+
+static int quantize_segments_impl(const void* src_bf16, const int64_t* seg_off, const int64_t* seg_n, int nseg, int64_t max_seg_n, void* dst_fp8,
+                                  float* amax, float* scale, const unsigned long long* step, int period, void* stream) {
     KVQ_REQUIRE(src_bf16 && seg_off && seg_n && dst_fp8 && amax && scale && nseg > 0 && max_seg_n > 0, "kvq_fp8_quantize_segments: bad argument");
     KVQ_REQUIRE((((uintptr_t)src_bf16 | (uintptr_t)dst_fp8) & 15) == 0, "kvq_fp8_quantize_segments: 16-byte aligned buffers");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(fp8_zero_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, amax, nseg);
+    hipLaunchKernelGGL(fp8_zero_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, amax, nseg, step, period);
     const int64_t chunks = max_seg_n / 8;
     unsigned gx = (unsigned)((chunks + Q_THREADS * 8 - 1) / (Q_THREADS * 8));
     gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
-    hipLaunchKernelGGL(fp8_seg_amax_kernel, dim3(gx, (unsigned)nseg), dim3(Q_THREADS), 0, st, (const unsigned short*)src_bf16, seg_off, seg_n, amax);
+    hipLaunchKernelGGL(fp8_seg_amax_kernel, dim3(gx, (unsigned)nseg), dim3(Q_THREADS), 0, st, (const unsigned short*)src_bf16, seg_off, seg_n, amax,
+                       step, period);
     hipLaunchKernelGGL(fp8_seg_quant_kernel, dim3(gx, (unsigned)nseg), dim3(Q_THREADS), 0, st, (const unsigned short*)src_bf16, seg_off, seg_n, amax,
                        (unsigned char*)dst_fp8, scale);
     return check_launch("fp8_seg_quant_kernel");

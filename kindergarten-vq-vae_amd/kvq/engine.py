@@ -542,8 +542,14 @@ class TrainEngine:
         # PRODUCING that input wrote beside the bf16 one (LayerNorm forward, attention forward, the GELU epilogue of the fp8
         # BertIntermediate GEMM: kvq_*_fp8) -- the 120 quantisation passes of "all" are gone; what still takes a pass is the input
         # of a layer-0 QKV projection (embedding kernel) and of the cross-K/V projection (quantiser output).
+        # Since round 5 this is what fp8_forward=True / KVQ_FP8=1 means (same box, nine codebooks, profiles/r05_fp8.md: 16.96 ms against
+        # 17.05 for "wide" and 17.14 for bf16); "wide" = rounds 4's two GEMMs, "all" = every GEMM behind a quantisation pass (A/B arm).
         if fp8_forward is None:
-            fp8_forward = {"0": False, "1": True, "all": "all", "fused": "fused"}.get(os.environ.get("KVQ_FP8", "0"), False)
+            fp8_forward = {"0": False, "1": True, "all": "all", "fused": "fused", "wide": "wide"}.get(os.environ.get("KVQ_FP8", "0"), False)
+        if fp8_forward is True:
+            fp8_forward = "fused"
+        if fp8_forward not in (False, "fused", "wide", "all"):
+            raise KvqError(f"TrainEngine: fp8_forward must be False, True / \"fused\", \"wide\" or \"all\", got {fp8_forward!r}")
         self.fp8 = bool(fp8_forward)
         self._fp8_fused = fp8_forward == "fused"
         self._fp8_all = fp8_forward in ("all", "fused")
@@ -644,7 +650,7 @@ class TrainEngine:
         keys = list(segs)
         if not keys:
             raise KvqError("TrainEngine: fp8 forward GEMMs asked for, but no weight of this model is wide enough for them to pay "
-                           f"(>= {self._FP8_MIN_ROWS} rows); use fp8_forward=\"all\" to put every forward GEMM on fp8")
+                           f"(>= {self._FP8_MIN_ROWS} rows); fp8_forward=True / \"fused\" puts every forward GEMM on fp8")
         self._w8_index = {k: i for i, k in enumerate(keys)}
         offs = [segs[k][0] for k in keys]
         ns = [segs[k][1] for k in keys]
@@ -653,6 +659,7 @@ class TrainEngine:
         self._w8_off = torch.tensor(offs, dtype=torch.int64, device=self.dev)
         self._w8_n = torch.tensor(ns, dtype=torch.int64, device=self.dev)
         self._w8_max = max(ns)
+        self._w8_period = max(int(os.environ.get("KVQ_FP8_W_PERIOD", "16")), 1)
         self._w8_amax = torch.zeros(len(keys), dtype=torch.float32, device=self.dev)
         self._w8_scale = torch.ones(len(keys), dtype=torch.float32, device=self.dev)
         self._fp8_quantize_weights()
@@ -670,8 +677,17 @@ class TrainEngine:
         """True when the kernel that produces the input of GEMM `key` should write its fp8 copy too (scope "fused")."""
         return self.fp8 and self._fp8_fused and key is not None and key in self._w8_index
 
-    def _fp8_quantize_weights(self):
-        """After every weight update: the GEMM weights of the whole model to fp8 in two launches."""
+    def _fp8_quantize_weights(self, in_step=False):
+        """The GEMM weights of the whole model to fp8 (two passes over the bf16 shadow: amax per weight, then the conversion).
+        in_step: after an optimiser step of the engine -- the amax pass (and with it the scales) runs on every
+        KVQ_FP8_W_PERIOD-th step only (default 16, decided from the device step count, so that graph replay follows): between
+        refreshes a weight that outgrew its amax saturates, and an Adam step moves a weight by ~lr."""
+        if in_step and self._w8_period > 1:
+            check(lib().kvq_fp8_quantize_segments_periodic(self.flat.shadow.data_ptr(), self._w8_off.data_ptr(), self._w8_n.data_ptr(),
+                                                           len(self._w8_index), self._w8_max, self._w8.data_ptr(), self._w8_amax.data_ptr(),
+                                                           self._w8_scale.data_ptr(), self._state.data_ptr(), self._w8_period, stream_ptr()),
+                  "kvq_fp8_quantize_segments_periodic")
+            return
         check(lib().kvq_fp8_quantize_segments(self.flat.shadow.data_ptr(), self._w8_off.data_ptr(), self._w8_n.data_ptr(), len(self._w8_index),
                                               self._w8_max, self._w8.data_ptr(), self._w8_amax.data_ptr(), self._w8_scale.data_ptr(),
                                               stream_ptr()), "kvq_fp8_quantize_segments")
@@ -1702,7 +1718,7 @@ class TrainEngine:
         if self.vq_kind in ("VectorQuantizer", "MultiVectorQuantizer") and self.E.requires_grad:
             self._repack_codebook()
         if self.fp8:
-            self._fp8_quantize_weights()
+            self._fp8_quantize_weights(in_step=True)
 
     def _versions(self):
         return sum(p._version for p in self.param_of.values())

@@ -60,10 +60,11 @@ def _build(seed=0):
     return Shelgon("kvq-bert-base-2l", vq, "kvq-bert-base-2l", None, compute_dtype=torch.bfloat16).cuda().eval()
 
 
-@pytest.mark.parametrize("scope", ["all", "fused", True])
+@pytest.mark.parametrize("scope", ["all", True, "wide"])
 def test_engine_fp8_forward_against_the_bf16_engine(scope):
-    """bert-base widths, 2 layers, 2048 tokens: forward GEMMs on the fp8 matrix cores -- every one ("all") or, the default of
-    fp8_forward=True, the two that pay for their quantisation pass (LM head, all-layer cross-K/V) --, backward in bf16.
+    """bert-base widths, 2 layers, 2048 tokens: forward GEMMs on the fp8 matrix cores -- every one, the inputs quantised by the kernels
+    that produce them (fp8_forward=True, round 5) or by a pass each ("all"), or only the two widest ("wide": LM head, all-layer
+    cross-K/V) --, backward in bf16.
     Stated tolerance: reconstruction loss within 2e-2 relative of the bf16 engine, VQ loss within 5e-2; gradients point the
     same way (cosine > 0.9 per tensor, > 0.98 on average)."""
     from dsentences.synthetic import random_token_batch
@@ -84,9 +85,9 @@ def test_engine_fp8_forward_against_the_bf16_engine(scope):
     assert min(cos) > 0.9 and np.mean(cos) > 0.98, (min(cos), np.mean(cos))
     # the weight mirror: every segment is the torch conversion of the bf16 shadow at that segment's own scale
     # (two decoder layers: the all-layer cross-K/V block is 3072 rows, below the width from which fp8 pays; at 12 layers it is 18432)
-    assert ("enc.0.f1.w" in e8._w8_index) == (scope in ("all", "fused")) and "dec.emb.word" in e8._w8_index
-    assert (e8._cakv_w[0] in e8._w8_index) == (scope in ("all", "fused"))
-    key = "enc.0.f1.w" if scope in ("all", "fused") else "dec.emb.word"
+    assert ("enc.0.f1.w" in e8._w8_index) == (scope != "wide") and "dec.emb.word" in e8._w8_index
+    assert (e8._cakv_w[0] in e8._w8_index) == (scope != "wide") and e8._fp8_fused == (scope is True)
+    key = "enc.0.f1.w" if scope != "wide" else "dec.emb.word"
     si, (o, n, shape) = e8._w8_index[key], e8.flat.seg[key]
     n = e8._w8_n[si].item()
     want, s = _ref_quant(e8.flat.shadow[o:o + n])
@@ -286,3 +287,47 @@ def test_fused_scope_equals_the_scope_with_quantisation_passes():
     sa, sf = ea._a8_state[:, 0].cpu().numpy(), ef._a8_state[:, 0].cpu().numpy()
     assert ea._w8_index == ef._w8_index
     np.testing.assert_allclose(sf, sa, rtol=5e-2)
+
+
+def test_periodic_weight_scales_follow_the_device_step_count():
+    """kvq_fp8_quantize_segments_periodic (round 5): inside the training step the per-weight amax pass runs only when the DEVICE step
+    count is a multiple of the period; between refreshes the bytes are the conversion with the scale of the last refresh
+    (saturating).  Captured once and replayed while the counter moves: the graph follows the counter."""
+    from kvq._ffi import check, lib, stream_ptr
+    nseg, seg_n, period = 6, 4096, 4
+    g = torch.Generator(device="cuda").manual_seed(1)
+    base = torch.randn(nseg * seg_n, device="cuda", generator=g)
+    src = base.to(torch.bfloat16)
+    off = torch.arange(nseg, device="cuda", dtype=torch.int64) * seg_n
+    n = torch.full((nseg,), seg_n, device="cuda", dtype=torch.int64)
+    dst = torch.zeros(nseg * seg_n, dtype=torch.uint8, device="cuda")
+    amax, scale = torch.zeros(nseg, device="cuda"), torch.ones(nseg, device="cuda")
+    step = torch.zeros(4, dtype=torch.int64, device="cuda")               # (a StepState: the count is its first 8 bytes)
+
+    def quantise():
+        check(lib().kvq_fp8_quantize_segments_periodic(src.data_ptr(), off.data_ptr(), n.data_ptr(), nseg, seg_n, dst.data_ptr(),
+                                                       amax.data_ptr(), scale.data_ptr(), step.data_ptr(), period, stream_ptr()), "periodic")
+    quantise()                                                            # step 0: a refresh
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        quantise()
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    held = None
+    for t in range(10):
+        step[0] = t
+        src.copy_((base * (1.0 + 0.5 * t)).to(torch.bfloat16))            # the weights grow: every refresh sees a larger amax
+        graph.replay()
+        torch.cuda.synchronize()
+        seg = src.view(nseg, seg_n).float()
+        if t % period == 0:
+            held = 448.0 / seg.abs().amax(dim=1)
+            torch.testing.assert_close(scale, held, rtol=1e-6, atol=0)
+        else:
+            torch.testing.assert_close(scale, held, rtol=1e-6, atol=0)   # unchanged since the last refresh
+        want = (seg * scale[:, None]).clamp(-448, 448).cpu().to(torch.float8_e4m3fn).float()
+        assert torch.equal(dst.view(nseg, seg_n).cpu().view(torch.float8_e4m3fn).float(), want), t

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# round 5: fp8 with the copies written by the producers -- tests, then bf16 / --fp8 / --fp8-fused / --fp8-all interleaved on one box (nine codebooks)
+# round 5: fp8 with the copies written by the producers -- tests, then bf16 / --fp8 / --fp8 / --fp8-all interleaved on one box (nine codebooks)
 set -uo pipefail
 mkdir -p gpurun_out/r5h
 timeout -k 10 900 python -m pytest tests/test_fp8_gpu.py tests/test_graph_nodes_gpu.py tests/test_dropres_gpu.py tests/test_nn_kernels_gpu.py -q -x --timeout 600 > gpurun_out/r5h/pytest.log 2>&1; rc=$?
@@ -8,7 +8,7 @@ tail -3 gpurun_out/r5h/pytest.log
 p() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['final_loss'], '%.3f ms @ %.0f MHz' % (d['ms_per_step'], d['clock_mhz']))"; }
 for i in 1 2 3; do
   python bench.py --no-cpu-baseline --steps 30 --factors 9 2>/dev/null | p "bf16      "
-  python bench.py --no-cpu-baseline --steps 30 --factors 9 --fp8 2>/dev/null | p "fp8 wide  "
-  python bench.py --no-cpu-baseline --steps 30 --factors 9 --fp8-fused 2>/dev/null | p "fp8 fused "
+  python bench.py --no-cpu-baseline --steps 30 --factors 9 --fp8-wide 2>/dev/null | p "fp8 wide  "
+  python bench.py --no-cpu-baseline --steps 30 --factors 9 --fp8 2>/dev/null | p "fp8 fused "
   [ $i -eq 1 ] && python bench.py --no-cpu-baseline --steps 30 --factors 9 --fp8-all 2>/dev/null | p "fp8 all   "
 done 2>&1 | tee gpurun_out/r5h/ab_fp8.txt

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 200 python bench.py --no-cpu-baseline --steps 40 --warmup 10 --family-steps 0 > gpurun_out/rccl1/bench_plain.json 2> gpurun_out/rccl1/plain.err
 KVQ_DP_SINGLE_RANK=1 timeout -k 10 200 python bench.py --no-cpu-baseline --steps 40 --warmup 10 --family-steps 0 > gpurun_out/rccl1/bench_rccl1.json 2> gpurun_out/rccl1/rccl1.err
 export KVQ_DP_SINGLE_RANK=1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rccl1/trace -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 --family-steps 0 > gpurun_out/rccl1/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rccl1/trace -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 --family-steps 0 --no-distance-phase > gpurun_out/rccl1/trace.log 2>&1
 python tools/step_breakdown.py gpurun_out/rccl1/trace 60 > gpurun_out/rccl1/breakdown.txt
 head -40 gpurun_out/rccl1/breakdown.txt
 python - <<'PY'

@@ -8,7 +8,7 @@ tag="${1:-r01}"
 out="gpurun_out/$tag"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$out"; mkdir -p "$out"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/step" -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 --family-steps 0 > "$out/step.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/step" -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 --family-steps 0 --no-distance-phase > "$out/step.log" 2>&1
 echo "step pass done"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python tools/vq_only.py > "$out/pmc_fetch.log" 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python tools/vq_only.py > "$out/pmc_write.log" 2>&1
