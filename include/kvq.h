@@ -395,6 +395,8 @@ int kvq_fp8_quantize_segments(const void* src_bf16, const int64_t* seg_off, cons
  * count *step_count_u64 is a multiple of `period`; on the steps between, the segments are quantised with the scale they have
  * (values that outgrew it saturate at +-448).  Weights move by ~lr per step: a period of 16 saves one of the two passes over the
  * weights on 15 steps of 16. */
+/* (period < -1: ALSO the conversion pass runs only on steps that are multiples of -period -- for a caller whose optimiser kernel
+ * writes the fp8 bytes itself on the other steps: kvq_adam_step_dev_fp8.) */
 int kvq_fp8_quantize_segments_periodic(const void* src_bf16, const int64_t* seg_off, const int64_t* seg_n, int nseg, int64_t max_seg_n,
                                        void* dst_fp8, float* amax, float* scale, const void* step_count_u64, int period, void* stream);
 int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const float* scale_b, const void* bias, void* C, int M, int N,
@@ -421,6 +423,14 @@ int kvq_gemm_fp8_nt_gelu(const void* A8, const void* B8, const float* scale_a, c
  *   p, m, v [, vmax] f32; g grad_dtype (scaled by grad_scale first); shadow_bf16 (may be NULL) receives bf16(p_new).
  *   step >= 1 is the 1-based step count for bias correction.  Any n >= 1 (16-byte aligned buffers; the last n %% 4 elements take a
  *   scalar path: the 9-code Gumbel bias of the reference's analysis run). */
+/* kvq_adam_step_dev that also writes the fp8 (e4m3) mirror of the GEMM weights inside [first_element, first_element + n) of the flat
+ * parameter buffer: w8_mirror is indexed like that buffer (one byte per element), span_segment[element >> 11] = the quantisation
+ * segment covering that 2048-element span (-1 none, -2 several things: the kernel then walks seg_off / seg_n), seg_scale the segments'
+ * current scales.  The bytes are kvq_fp8_quantize_segments' for the bf16 value the update stores in the shadow. */
+int kvq_adam_step_dev_fp8(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
+                          const void* step_state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                          void* w8_mirror, const int* span_segment, const float* seg_scale, const int64_t* seg_off, const int64_t* seg_n,
+                          int nseg, int64_t first_element, void* stream);
 int kvq_adam_step(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                   void* stream);

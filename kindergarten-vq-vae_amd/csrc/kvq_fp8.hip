@@ -60,7 +60,10 @@ __global__ __launch_bounds__(Q_THREADS) void fp8_seg_amax_kernel(const unsigned 
 
 __global__ __launch_bounds__(Q_THREADS) void fp8_seg_quant_kernel(const unsigned short* __restrict__ src, const int64_t* __restrict__ off,
                                                                    const int64_t* __restrict__ n, const float* __restrict__ amax,
-                                                                   unsigned char* __restrict__ dst, float* __restrict__ scale) {
+                                                                   unsigned char* __restrict__ dst, float* __restrict__ scale,
+                                                                   const unsigned long long* __restrict__ step = nullptr, int period = 1) {
+    // (period < 0: the conversion is gated like the amax pass -- the Adam kernel wrote this step's bytes with the scales in force)
+    if (step && period < -1 && (*step % (unsigned long long)(-period)) != 0) return;
     const int s = blockIdx.y;
     const int64_t chunks = n[s] >> 3;
     const float sc = scale_of(amax[s]);
@@ -206,7 +209,7 @@ int kvq_fp8_quantize_segments(const void* src_bf16, const int64_t* seg_off, cons
 
 int kvq_fp8_quantize_segments_periodic(const void* src_bf16, const int64_t* seg_off, const int64_t* seg_n, int nseg, int64_t max_seg_n,
                                        void* dst_fp8, float* amax, float* scale, const void* step_count_u64, int period, void* stream) {
-    KVQ_REQUIRE(step_count_u64 && period >= 1, "kvq_fp8_quantize_segments_periodic: a device step counter and period >= 1");
+    KVQ_REQUIRE(step_count_u64 && (period >= 1 || period < -1), "kvq_fp8_quantize_segments_periodic: a device step counter and |period| >= 1");
     return quantize_segments_impl(src_bf16, seg_off, seg_n, nseg, max_seg_n, dst_fp8, amax, scale, (const unsigned long long*)step_count_u64,
                                   period, stream);
 }
@@ -216,14 +219,15 @@ static int quantize_segments_impl(const void* src_bf16, const int64_t* seg_off, 
     KVQ_REQUIRE(src_bf16 && seg_off && seg_n && dst_fp8 && amax && scale && nseg > 0 && max_seg_n > 0, "kvq_fp8_quantize_segments: bad argument");
     KVQ_REQUIRE((((uintptr_t)src_bf16 | (uintptr_t)dst_fp8) & 15) == 0, "kvq_fp8_quantize_segments: 16-byte aligned buffers");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(fp8_zero_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, amax, nseg, step, period);
+    const int gate = period < 0 ? -period : period;          // period < 0: also the conversion pass runs on refresh steps only
+    hipLaunchKernelGGL(fp8_zero_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, amax, nseg, step, gate);
     const int64_t chunks = max_seg_n / 8;
     unsigned gx = (unsigned)((chunks + Q_THREADS * 8 - 1) / (Q_THREADS * 8));
     gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
     hipLaunchKernelGGL(fp8_seg_amax_kernel, dim3(gx, (unsigned)nseg), dim3(Q_THREADS), 0, st, (const unsigned short*)src_bf16, seg_off, seg_n, amax,
-                       step, period);
+                       step, gate);
     hipLaunchKernelGGL(fp8_seg_quant_kernel, dim3(gx, (unsigned)nseg), dim3(Q_THREADS), 0, st, (const unsigned short*)src_bf16, seg_off, seg_n, amax,
-                       (unsigned char*)dst_fp8, scale);
+                       (unsigned char*)dst_fp8, scale, step, period);
     return check_launch("fp8_seg_quant_kernel");
 }
 

@@ -1399,8 +1399,25 @@ int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const 
     kvq_gemm_problem q;                         // the ring moves bytes: an fp8 row of K elements is a bf16 row of K / 2
     q.A = A8; q.B = B8; q.C = C; q.bias = bias; q.M = M; q.N = N; q.K = K / 2; q.lda = lda / 2; q.ldb = ldb / 2; q.ldc = ldc; q.accumulate = 0;
     g2::Params P;
-    if (int rc = build_params(&q, 1, KVQ_GEMM_NT, KVQ_GEMM_TILE_128x256, P, "kvq_gemm_fp8_nt")) return rc;
+    // Tile (round 5): 128 x 256 unless that leaves CUs without a tile and 128 x 192 does not -- an [8192, 768] output is 192 tiles of
+    // the first and 256 of the second (KVQ_FP8_TILE=0: always 128 x 256, the rounds 2 - 4 behaviour; A/B switch)
+    static const bool narrow_ok = !(getenv("KVQ_FP8_TILE") && atoi(getenv("KVQ_FP8_TILE")) == 0);
+    const int t256 = ((M + 127) / 128) * ((N + 255) / 256), t192 = ((M + 127) / 128) * ((N + 191) / 192);
+    const bool narrow = narrow_ok && t256 < g2::persistent_grid() && t192 > t256;
+    if (int rc = build_params(&q, 1, KVQ_GEMM_NT, narrow ? KVQ_GEMM_TILE_128x192 : KVQ_GEMM_TILE_128x256, P, "kvq_gemm_fp8_nt")) return rc;
     for (int i = 0; i < g2::MAX_PROBLEMS; ++i) { P.p[i].scaleA = scale_a; P.p[i].scaleB = scale_b; }
+    hipStream_t st = (hipStream_t)stream;
+    if (narrow) {
+        typedef g2::Cfg128x192<true, true> Cn;
+        static std::atomic<bool> attr_n{false};
+        if (!attr_n) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&g2::gemm2_f8_kernel<Cn>), hipFuncAttributeMaxDynamicSharedMemorySize, Cn::LDS);
+            if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm2_f8 128x192): %s", hipGetErrorString(e));
+            attr_n = true;
+        }
+        hipLaunchKernelGGL((g2::gemm2_f8_kernel<Cn>), dim3((unsigned)P.ntiles), dim3(Cn::THREADS), Cn::LDS, st, P);
+        return check_launch("gemm2_f8_kernel<128x192>");
+    }
     typedef g2::Cfg128x256<true, true> Cf;
     static std::atomic<bool> attr_done{false};
     if (!attr_done) {
@@ -1408,7 +1425,7 @@ int kvq_gemm_fp8_nt(const void* A8, const void* B8, const float* scale_a, const 
         if (e != hipSuccess) return fail(KVQ_E_LAUNCH, "hipFuncSetAttribute(gemm2_f8): %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((g2::gemm2_f8_kernel<Cf>), dim3((unsigned)P.ntiles), dim3(Cf::THREADS), Cf::LDS, (hipStream_t)stream, P);
+    hipLaunchKernelGGL((g2::gemm2_f8_kernel<Cf>), dim3((unsigned)P.ntiles), dim3(Cf::THREADS), Cf::LDS, st, P);
     return check_launch("gemm2_f8_kernel");
 }
 

@@ -807,6 +807,21 @@ __device__ __forceinline__ void adam_update4(f32x4& pv, f32x4 gv, f32x4& mv, f32
     pv.z -= step * (mv.z / den.z); pv.w -= step * (mv.w / den.w);
 }
 
+// Optional (round 5, fp8 forward GEMMs): the fp8 (e4m3) mirror of the GEMM weights written by the update itself, from the bf16 value
+// it has just rounded for the shadow -- instead of a conversion pass over the whole shadow buffer after every step.  The mirror is
+// indexed like the flat parameter buffer (one byte per element); `gseg[global element >> 11]` names the quantisation segment (= GEMM
+// weight, one scale each) that covers a 2048-element span: >= 0 the segment, -1 none, -2 more than one thing (the thread then walks
+// the segment table).  Segments start and end at multiples of 16 elements, so a thread's 8 elements never straddle one.
+struct AdamFp8 {
+    unsigned char* w8;            // null: no mirror
+    const int* gseg;
+    const float* scale;           // [nseg] current scales (kvq_fp8_quantize_segments*)
+    const int64_t* seg_off;       // [nseg] first element of each segment
+    const int64_t* seg_n;         // [nseg]
+    int nseg;
+    int64_t e_base;               // global element index of p[0]
+};
+
 // 8 parameters per thread and pass: every array moves in 16-byte accesses (the bf16 gradient and shadow included), two
 // independent 4-element updates in flight.  n8 = n / 8 chunks; a tail of 4 (n % 8 == 4) is handled by the last thread.
 template <int DT_G>
@@ -814,7 +829,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                     float* __restrict__ v, float* __restrict__ vmax,
                                                     unsigned short* __restrict__ shadow, int64_t n4, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    float grad_scale, const float* __restrict__ hyper, int n_tail) {
+                                                    float grad_scale, const float* __restrict__ hyper, int n_tail, AdamFp8 f8) {
     if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }     // device-resident step state (kvq_step_state_advance)
     const int64_t n8 = n4 >> 1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
@@ -829,6 +844,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         *reinterpret_cast<f32x4*>(m + e) = m0; *reinterpret_cast<f32x4*>(m + e + 4) = m1;
         *reinterpret_cast<f32x4*>(v + e) = v0; *reinterpret_cast<f32x4*>(v + e + 4) = v1;
         if (shadow) { f32x8 o = {p0, p1}; IO<KVQ_BF16>::store8(shadow, e, o); }
+        if (f8.w8) {                                                        // (uniform)
+            const int64_t ge = f8.e_base + e;
+            int sg = f8.gseg[ge >> 11];
+            if (sg == -2) {
+                sg = -1;
+                for (int q = 0; q < f8.nseg; ++q)
+                    if (ge >= f8.seg_off[q] && ge < f8.seg_off[q] + f8.seg_n[q]) sg = q;
+            }
+            if (sg >= 0) {
+                const uint4 r = {(unsigned)f32_to_bf16(p0.x) | ((unsigned)f32_to_bf16(p0.y) << 16), (unsigned)f32_to_bf16(p0.z) | ((unsigned)f32_to_bf16(p0.w) << 16),
+                                 (unsigned)f32_to_bf16(p1.x) | ((unsigned)f32_to_bf16(p1.y) << 16), (unsigned)f32_to_bf16(p1.z) | ((unsigned)f32_to_bf16(p1.w) << 16)};
+                *reinterpret_cast<uint2*>(f8.w8 + ge) = quant8(r, f8.scale[sg]);
+            }
+        }
     }
     if ((n4 & 1) && blockIdx.x == 0 && threadIdx.x == 0) {                  // the odd 4-element chunk
         const int64_t e = 4 * (n4 - 1);
@@ -2708,7 +2737,7 @@ int kvq_gelu_bwd(const void* h, const void* g_a, void* g_h, int64_t n, int io_dt
 
 static int adam_launch(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
                        float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2s, float grad_scale,
-                       const float* hyper, void* stream) {
+                       const float* hyper, void* stream, AdamFp8 f8 = AdamFp8{}) {
     KVQ_REQUIRE(p && g && m && v && n > 0, "kvq_adam_step: bad argument");
     KVQ_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax | (uintptr_t)shadow_bf16) & 15) == 0,
                 "kvq_adam_step: 16-byte aligned buffers required");
@@ -2720,9 +2749,9 @@ static int adam_launch(float* p, const void* g, float* m, float* v, float* vmax,
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DT(grad_dtype,
                 hipLaunchKernelGGL(adam_kernel<KVQ_F32>, dim3(blocks), dim3(256), 0, st, p, g, m, v, vmax, (unsigned short*)shadow_bf16, n4,
-                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper, n_tail),
+                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper, n_tail, f8),
                 hipLaunchKernelGGL(adam_kernel<KVQ_BF16>, dim3(blocks), dim3(256), 0, st, p, g, m, v, vmax, (unsigned short*)shadow_bf16, n4,
-                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper, n_tail));
+                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, hyper, n_tail, f8));
     return check_launch("adam_kernel");
 }
 
@@ -2741,6 +2770,21 @@ int kvq_adam_step_dev(float* p, const void* g, float* m, float* v, float* vmax, 
     KVQ_REQUIRE(step_state, "kvq_adam_step_dev: null step state");
     return adam_launch(p, g, m, v, vmax, shadow_bf16, n, grad_dtype, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale,
                        reinterpret_cast<const float*>(reinterpret_cast<const char*>(step_state) + 8), stream);
+}
+
+int kvq_adam_step_dev_fp8(float* p, const void* g, float* m, float* v, float* vmax, void* shadow_bf16, int64_t n, int grad_dtype,
+                          const void* step_state, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                          void* w8_mirror, const int* span_segment, const float* seg_scale, const int64_t* seg_off, const int64_t* seg_n,
+                          int nseg, int64_t first_element, void* stream) {
+    KVQ_REQUIRE(step_state && shadow_bf16, "kvq_adam_step_dev_fp8: step state and bf16 shadow required");
+    KVQ_REQUIRE(w8_mirror && span_segment && seg_scale && seg_off && seg_n && nseg > 0, "kvq_adam_step_dev_fp8: null fp8 argument");
+    KVQ_REQUIRE(first_element >= 0 && first_element % 8 == 0 && n % 8 == 0 && ((uintptr_t)w8_mirror & 7) == 0,
+                "kvq_adam_step_dev_fp8: the range must start and end at multiples of 8 elements");
+    AdamFp8 f8;
+    f8.w8 = (unsigned char*)w8_mirror; f8.gseg = span_segment; f8.scale = seg_scale; f8.seg_off = seg_off; f8.seg_n = seg_n; f8.nseg = nseg;
+    f8.e_base = first_element;
+    return adam_launch(p, g, m, v, vmax, shadow_bf16, n, grad_dtype, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale,
+                       reinterpret_cast<const float*>(reinterpret_cast<const char*>(step_state) + 8), stream, f8);
 }
 
 static int step_state_launch(void* step_state, float lr0, float gamma, const int64_t* milestones, int n_milestones, float beta1,

@@ -99,6 +99,7 @@ SIGNATURES = {
     "kvq_fp8_quantize_delayed": (_int, [_vp, _i64, _int, _i64, _vp, _vp, _vp]),
     "kvq_fp8_update_scales": (_int, [_vp, _int, _f32, _vp]),
     "kvq_fp8_quantize_segments": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp]),
+    "kvq_adam_step_dev_fp8": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]),
     "kvq_fp8_quantize_segments_periodic": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
     "kvq_gemm_fp8_nt": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _vp]),
     "kvq_dropout_residual_ln_fwd_fp8": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f32, _f32, C.c_uint64, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

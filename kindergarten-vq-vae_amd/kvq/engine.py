@@ -660,6 +660,19 @@ class TrainEngine:
         self._w8_n = torch.tensor(ns, dtype=torch.int64, device=self.dev)
         self._w8_max = max(ns)
         self._w8_period = max(int(os.environ.get("KVQ_FP8_W_PERIOD", "16")), 1)
+        # the Adam kernel writes the fp8 mirror itself (kvq_adam_step_dev_fp8) when the scales are not refreshed on every step:
+        # span_segment[e >> 11] = the segment covering elements [2048 k, 2048 k + 2048), -1 none, -2 several things
+        self._w8_in_adam = self._w8_period > 1 and os.environ.get("KVQ_FP8_ADAM", "1") != "0"
+        import numpy as _np
+        nspan = (fl.n + 2047) // 2048
+        span = _np.full(nspan, -1, dtype=_np.int32)
+        for si, (o, n) in enumerate(zip(offs, ns)):
+            k0, k1 = o // 2048, (o + n - 1) // 2048
+            for k in range(k0, k1 + 1):
+                lo, hi = 2048 * k, min(2048 * k + 2048, fl.n)
+                whole = o <= lo and o + n >= hi
+                span[k] = si if (whole and span[k] == -1) else -2
+        self._w8_span = torch.from_numpy(span).to(self.dev)
         self._w8_amax = torch.zeros(len(keys), dtype=torch.float32, device=self.dev)
         self._w8_scale = torch.ones(len(keys), dtype=torch.float32, device=self.dev)
         self._fp8_quantize_weights()
@@ -683,9 +696,11 @@ class TrainEngine:
         KVQ_FP8_W_PERIOD-th step only (default 16, decided from the device step count, so that graph replay follows): between
         refreshes a weight that outgrew its amax saturates, and an Adam step moves a weight by ~lr."""
         if in_step and self._w8_period > 1:
+            # (negative period: the Adam kernel has written this step's bytes, the conversion pass runs on refresh steps only)
+            per = -self._w8_period if self._w8_in_adam else self._w8_period
             check(lib().kvq_fp8_quantize_segments_periodic(self.flat.shadow.data_ptr(), self._w8_off.data_ptr(), self._w8_n.data_ptr(),
                                                            len(self._w8_index), self._w8_max, self._w8.data_ptr(), self._w8_amax.data_ptr(),
-                                                           self._w8_scale.data_ptr(), self._state.data_ptr(), self._w8_period, stream_ptr()),
+                                                           self._w8_scale.data_ptr(), self._state.data_ptr(), per, stream_ptr()),
                   "kvq_fp8_quantize_segments_periodic")
             return
         check(lib().kvq_fp8_quantize_segments(self.flat.shadow.data_ptr(), self._w8_off.data_ptr(), self._w8_n.data_ptr(), len(self._w8_index),
@@ -1655,7 +1670,15 @@ class TrainEngine:
         b1, b2 = self.betas
         for (a, b) in fl.ranges:
             a, b = max(a, lo), min(b, hi)
-            if a < b:
+            if a < b and self.fp8 and self._w8_in_adam and a % 8 == 0 and b % 8 == 0 and fl.shadow is not fl.master:
+                # the update also writes the fp8 mirror of the GEMM weights in [a, b) (scales of the last refresh)
+                check(lib().kvq_adam_step_dev_fp8(fl.master[a:b].data_ptr(), fl.grad[a:b].data_ptr(), fl.m[a:b].data_ptr(), fl.v[a:b].data_ptr(),
+                                                  fl.vmax[a:b].data_ptr() if fl.vmax is not None else None, fl.shadow[a:b].data_ptr(), b - a,
+                                                  nnops.io_dtype_of(fl.grad), self._state.data_ptr(), b1, b2, self.eps, self.wd, 1.0,
+                                                  self._w8.data_ptr(), self._w8_span.data_ptr(), self._w8_scale.data_ptr(),
+                                                  self._w8_off.data_ptr(), self._w8_n.data_ptr(), len(self._w8_index), a, stream_ptr()),
+                      "kvq_adam_step_dev_fp8")
+            elif a < b:
                 nnops.adam_step_dev(fl.master[a:b], fl.grad[a:b], fl.m[a:b], fl.v[a:b], self._state, b1, b2, self.eps, self.wd,
                                     vmax=fl.vmax[a:b] if fl.vmax is not None else None,
                                     shadow=fl.shadow[a:b] if fl.shadow is not fl.master else None)

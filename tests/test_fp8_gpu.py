@@ -331,3 +331,52 @@ def test_periodic_weight_scales_follow_the_device_step_count():
             torch.testing.assert_close(scale, held, rtol=1e-6, atol=0)   # unchanged since the last refresh
         want = (seg * scale[:, None]).clamp(-448, 448).cpu().to(torch.float8_e4m3fn).float()
         assert torch.equal(dst.view(nseg, seg_n).cpu().view(torch.float8_e4m3fn).float(), want), t
+
+
+def test_adam_kernel_writes_the_fp8_mirror_of_the_weights_it_updates():
+    """kvq_adam_step_dev_fp8 (round 5): the optimiser kernel writes the e4m3 mirror of the GEMM weights from the bf16 value it stores in
+    the shadow, with the scales in force -- the bytes of a conversion pass over the new shadow; elements outside every segment are
+    left alone; the master / moments / shadow equal the plain kernel's."""
+    from kvq import nnops
+    from kvq._ffi import check, lib, stream_ptr
+    n = 6 * 2048 + 512
+    segs = [(16, 2048), (2064 + 496, 4096 + 1024), (11 * 1024, 1024)]            # starts / lengths in multiples of 16, spans cut anywhere
+    g = torch.Generator(device="cuda").manual_seed(3)
+    p0 = torch.randn(n, device="cuda", generator=g) * 0.05
+    grad = (torch.randn(n, device="cuda", generator=g) * 0.01).to(torch.bfloat16)
+    off = torch.tensor([o for o, _ in segs], dtype=torch.int64, device="cuda")
+    cnt = torch.tensor([c for _, c in segs], dtype=torch.int64, device="cuda")
+    scale = torch.tensor([300.0, 2000.0, 900.0], device="cuda")
+    span = torch.full(((n + 2047) // 2048,), -1, dtype=torch.int32)
+    for si, (o, c) in enumerate(segs):
+        for k in range(o // 2048, (o + c - 1) // 2048 + 1):
+            lo, hi = 2048 * k, min(2048 * k + 2048, n)
+            span[k] = si if (o <= lo and o + c >= hi and span[k] == -1) else -2
+    span = span.cuda()
+    state = nnops.new_step_state("cuda")
+    nnops.step_state_advance(state, 1e-3, 0.1, [], 0.9, 0.999)
+    runs = []
+    for fused in (False, True):
+        p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        shadow = p.to(torch.bfloat16)
+        w8 = torch.full((n,), 0xAB, dtype=torch.uint8, device="cuda")
+        if fused:
+            lo, hi = 8, n - 8                                   # a range that starts inside the first span (as the engine's chunks do)
+            nnops.adam_step_dev(p[:lo], grad[:lo], m[:lo], v[:lo], state, shadow=shadow[:lo])
+            check(lib().kvq_adam_step_dev_fp8(p[lo:hi].data_ptr(), grad[lo:hi].data_ptr(), m[lo:hi].data_ptr(), v[lo:hi].data_ptr(), None,
+                                              shadow[lo:hi].data_ptr(), hi - lo, 1, state.data_ptr(), 0.9, 0.999, 1e-8, 0.0, 1.0,
+                                              w8.data_ptr(), span.data_ptr(), scale.data_ptr(), off.data_ptr(), cnt.data_ptr(), len(segs), lo,
+                                              stream_ptr()), "kvq_adam_step_dev_fp8")
+            nnops.adam_step_dev(p[hi:], grad[hi:], m[hi:], v[hi:], state, shadow=shadow[hi:])
+        else:
+            nnops.adam_step_dev(p, grad, m, v, state, shadow=shadow)
+        torch.cuda.synchronize()
+        runs.append((p, m, v, shadow, w8))
+    (p_a, m_a, v_a, s_a, _), (p_b, m_b, v_b, s_b, w8) = runs
+    assert torch.equal(p_a, p_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b) and torch.equal(s_a.view(torch.int16), s_b.view(torch.int16))
+    inside = torch.zeros(n, dtype=torch.bool)
+    for si, (o, c) in enumerate(segs):
+        want = (s_b[o:o + c].float() * scale[si]).clamp(-448, 448).cpu().to(torch.float8_e4m3fn).float()
+        assert torch.equal(w8[o:o + c].cpu().view(torch.float8_e4m3fn).float(), want), si
+        inside[o:o + c] = True
+    assert bool((w8.cpu()[~inside] == 0xAB).all())                               # nothing written outside the segments
