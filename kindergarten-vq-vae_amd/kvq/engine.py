@@ -1670,7 +1670,9 @@ class TrainEngine:
         b1, b2 = self.betas
         for (a, b) in fl.ranges:
             a, b = max(a, lo), min(b, hi)
-            if a < b and self.fp8 and self._w8_in_adam and a % 8 == 0 and b % 8 == 0 and fl.shadow is not fl.master:
+            if a < b and self.fp8 and self._w8_in_adam:
+                if a % 8 or b % 8:           # (segments and chunk cuts are multiples of 16: cannot happen; a silent fallback would
+                    raise KvqError(f"TrainEngine: Adam range [{a}, {b}) is not 8-aligned")       # leave the fp8 mirror stale)
                 # the update also writes the fp8 mirror of the GEMM weights in [a, b) (scales of the last refresh)
                 check(lib().kvq_adam_step_dev_fp8(fl.master[a:b].data_ptr(), fl.grad[a:b].data_ptr(), fl.m[a:b].data_ptr(), fl.v[a:b].data_ptr(),
                                                   fl.vmax[a:b].data_ptr() if fl.vmax is not None else None, fl.shadow[a:b].data_ptr(), b - a,
