@@ -48,6 +48,7 @@ LIM_BATCHES_VAL_PCT = 1.0
 LIM_BATCHES_TEST_PCT = 1.0
 GRAD_BUCKET_MIB = 64
 USE_ENGINE = True               # kvq.engine.TrainEngine (explicit fwd/bwd on flat buffers, own HIP kernels) when the model shape allows
+FP8_FORWARD = False             # extension (BASELINE.json configs[4]): forward GEMMs on the fp8 matrix cores -- False | True | "wide" | "all"
 
 RUNS_DIR = "./runs/Bagon"
 EXPORT_CHECKPOINT = True

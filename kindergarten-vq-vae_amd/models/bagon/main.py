@@ -89,7 +89,8 @@ def main():
         # explicit forward/backward schedule on flat buffers (kvq/engine.py): own MFMA GEMMs and attention, fused loss, Adam, the
         # scheduler tick and the RCCL gradient exchange; `opt` above is then only the reference-shaped handle in run_conf.json
         engine = TrainEngine(model, lr=LR, weight_decay=WEIGHT_DECAY, amsgrad=AMSGRAD,
-                             milestones=MILESTONES if LR_SCHEDULER == "MultiStepLR" else None, gamma=GAMMA, bucket_mib=GRAD_BUCKET_MIB)
+                             milestones=MILESTONES if LR_SCHEDULER == "MultiStepLR" else None, gamma=GAMMA, bucket_mib=GRAD_BUCKET_MIB,
+                             fp8_forward=FP8_FORWARD if FP8_FORWARD else None)       # (None: the KVQ_FP8 environment switch decides)
         if TOKEN_CACHE and same_tok:
             for c in caches:
                 c.packed_pad_id = engine.pad_idx if not any_perturb else "off"     # perturbed ids are sorted by the engine itself

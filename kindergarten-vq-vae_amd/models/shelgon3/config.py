@@ -33,6 +33,7 @@ CROSS_ATTN_MAKE_TRAINABLE = False
 MODEL_MODE = "full"                  # full | dec-head-ft | enc-head-ft-dec-head-ft | vq-ft
 COMPUTE_DTYPE = "bfloat16"           # bfloat16 | float32
 USE_ENGINE = True                    # kvq.engine.TrainEngine (explicit fwd/bwd on flat buffers) when the model shape allows
+FP8_FORWARD = False                  # extension (BASELINE.json configs[4]): forward GEMMs on the fp8 matrix cores -- False | True | "wide" | "all"
 
 VQ_MODE = "VectorQuantizer"          # VectorQuantizer | GumbelQuantizer | MultiVectorQuantizer (extension: VQ_N_FACTORS codebooks)
 VQ_N_FACTORS = 1                     # MultiVectorQuantizer: codebooks = slices of the encoder output (must divide VQ_E_DIM)

@@ -111,7 +111,8 @@ def main():
         engine = TrainEngine(model, lr=LR, weight_decay=WEIGHT_DECAY, amsgrad=AMSGRAD,
                              milestones=MILESTONES if LR_SCHEDULER == "MultiStepLR" else None, gamma=GAMMA,
                              loss_recon_scale=LOSS_RECON_RESCALE_FACTOR * LOSS_RECON_WEIGHT,
-                             loss_vq_scale=LOSS_VQ_RESCALE_FACTOR * LOSS_VQ_WEIGHT, bucket_mib=GRAD_BUCKET_MIB)
+                             loss_vq_scale=LOSS_VQ_RESCALE_FACTOR * LOSS_VQ_WEIGHT, bucket_mib=GRAD_BUCKET_MIB,
+                             fp8_forward=FP8_FORWARD if FP8_FORWARD else None)       # (None: the KVQ_FP8 environment switch decides)
         if TOKEN_CACHE:
             for c in caches:          # the packed sort files the MODEL's padding row under -1 (not the tokenizer's pad id)
                 c.packed_pad_id = engine.pad_idx

@@ -57,6 +57,22 @@ def test_shelgon_main_end_to_end(tmp_path, use_engine):
     assert {"epoch", "stage", "input_sentence", "recon_sentence"} <= set(df.columns) and len(df) > 0
 
 
+def test_shelgon_main_with_fp8_forward_gemms(tmp_path):
+    """FP8_FORWARD = True in models/shelgon3/config.py (BASELINE.json configs[4], extension): the entry point trains with every forward
+    GEMM of 384 x 128 activations on the fp8 matrix cores, the fp8 copies written by their producers, the weights' mirror by Adam."""
+    run = _run("models/shelgon3/main.py", tmp_path, lambda d: {
+        "KVQ_SENTENCES_PATH": repr(d + "/dSentences_sentences_clean.npy"),
+        "KVQ_LATENT_CLASSES_LABELS_PATH": repr(d + "/dSentences_latent_classes_labels_clean.npy"),
+        "KVQ_LATENT_CLASSES_ONE_HOT_PATH": repr(d + "/dSentences_latent_classes_one_hot_clean.npy"),
+        "KVQ_VQ_N_E": "32", "KVQ_VQ_E_DIM": "128", "KVQ_FP8_FORWARD": "True"})
+    conf = json.load(open(run + "/run_conf.json"))
+    assert conf["fp8_forward"] is True and conf["use_engine"]
+    logs = [json.loads(l) for l in open(run + "/metrics.jsonl")]
+    tr = [l["train/loss_recon"] for l in logs if "train/loss_recon" in l]
+    assert len(tr) == 2 and tr[1] < tr[0]
+    assert {"val", "test"} <= {k.split("/")[0] for l in logs for k in l if "/" in k}
+
+
 def test_shelgon_main_with_sentences_padded_to_40_tokens(tmp_path):
     """TOKENIZED_SENTENCE_MAX_LENGTH = 40: above the 32-token attention kernels, so the engine's step runs the blocked ones; the run
     trains and writes the usual artefacts."""
