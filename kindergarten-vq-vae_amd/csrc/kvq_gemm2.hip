@@ -1156,6 +1156,16 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm2_f8_kernel(Params P)
     epilogue<C, EPI>(pr, smem, acc, biasv, tid, lane, wm, wn, m0, n0, ti.tm, mul);
 }
 
+
+// (Round 5, measured and removed: a STAGGERED form of the 256 x 256 tile -- the guide's "256^2 eight-phase" idiom: four phases per k-tile
+//  (one quadrant of the wave tile = 16 MFMAs each), a phase = fragment reads + two DMA pieces | barrier | MFMAs | barrier, the two wave
+//  rows one barrier apart so that one is in its MFMA block while the other reads.  Bit-identical to the kernels above and 2 - 13 %
+//  SLOWER everywhere: grouped weight gradients of two decoder layers 252.9 against 223.9 us, [18432, 768] x 8192 206 against 195, LM
+//  head 366 against 340, 8192^3 1512 against 1535 TF (profiles/r05_probe_staggered.txt).  Eight barriers per k-tile cost more than
+//  the one barrier's bubble; with two waves per SIMD the intra-wave overlap of reads and MFMAs above is the better use of the pipe.
+//  On the guide's own reference problems the kernels above hold 1357 / 1377 TF at 4096^3 and 1535 TF at 8192^3 (its template: 1320 - 1340
+//  and ~1470; hipBLASLt: 1459 and 1621).)
+
 // ---- tile configurations ---------------------------------------------------------------------------------------------
 //                 BM   BN  WM WN  A k-major  B k-major  ring
 template <bool AK, bool BKM> using Cfg128x256 = Cfg<128, 256, 2, 4, AK, BKM, 3>;     // 8 waves, 144 KiB: one tile per CU (wgrad)
