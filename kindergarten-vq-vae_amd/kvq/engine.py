@@ -55,6 +55,23 @@ def engine_of(model, create=True):
     return eng
 
 
+def fp8_span_table(offs, ns, n_total, span=2048):
+    """span_segment of kvq_adam_step_dev_fp8 (include/kvq.h): for every `span`-element stretch of the flat parameter buffer the
+    quantisation segment (offs[i], ns[i]) that covers ALL of it, -1 when no segment touches it, -2 when it holds a segment boundary
+    (the kernel then walks the segment table for its 8 elements).  Segments must not overlap."""
+    import numpy as np
+    table = np.full((n_total + span - 1) // span, -1, dtype=np.int32)
+    for si, (o, n) in enumerate(zip(offs, ns)):
+        if n <= 0:
+            continue
+        k0, k1 = o // span, (o + n - 1) // span
+        for k in range(k0, k1 + 1):
+            lo, hi = span * k, min(span * k + span, n_total)
+            whole = o <= lo and o + n >= hi
+            table[k] = si if (whole and table[k] == -1) else -2
+    return table
+
+
 class _EngineForward(torch.autograd.Function):
     """model.forward with autograd ON, on the engine's kernels: forward = TrainEngine.forward_backward(defer_backward=True),
     backward = TrainEngine.backward_from(d logits, d loss_vq).  The model's parameters are the function's inputs, so autograd
@@ -663,16 +680,7 @@ class TrainEngine:
         # the Adam kernel writes the fp8 mirror itself (kvq_adam_step_dev_fp8) when the scales are not refreshed on every step:
         # span_segment[e >> 11] = the segment covering elements [2048 k, 2048 k + 2048), -1 none, -2 several things
         self._w8_in_adam = self._w8_period > 1 and os.environ.get("KVQ_FP8_ADAM", "1") != "0"
-        import numpy as _np
-        nspan = (fl.n + 2047) // 2048
-        span = _np.full(nspan, -1, dtype=_np.int32)
-        for si, (o, n) in enumerate(zip(offs, ns)):
-            k0, k1 = o // 2048, (o + n - 1) // 2048
-            for k in range(k0, k1 + 1):
-                lo, hi = 2048 * k, min(2048 * k + 2048, fl.n)
-                whole = o <= lo and o + n >= hi
-                span[k] = si if (whole and span[k] == -1) else -2
-        self._w8_span = torch.from_numpy(span).to(self.dev)
+        self._w8_span = torch.from_numpy(fp8_span_table(offs, ns, fl.n)).to(self.dev)
         self._w8_amax = torch.zeros(len(keys), dtype=torch.float32, device=self.dev)
         self._w8_scale = torch.ones(len(keys), dtype=torch.float32, device=self.dev)
         self._fp8_quantize_weights()

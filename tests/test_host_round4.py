@@ -102,3 +102,32 @@ def test_token_cache_hands_out_labels_and_respects_the_packed_pad_id():
     c2 = cache_of_split(Split(ds, [5, 2, 9]), tok, 12, False, "cpu", keep_labels=True)
     assert len(c2) == 3 and torch.equal(c2.labels, torch.as_tensor(labels)[[5, 2, 9]])
     assert cache_of_split(Split(ds, [5, 2, 9]), tok, 12, False, "cpu").labels is None
+
+
+def test_fp8_span_table_names_the_segment_of_every_span():
+    """kvq.engine.fp8_span_table (round 5): the table the Adam kernel reads to find the fp8 scale of the 8 weights it has just updated
+    (kvq_adam_step_dev_fp8).  For random non-overlapping segments in multiples of 16: a span wholly inside one segment names it, a
+    span no segment touches is -1, everything else -2 -- and walking the segment table for the -2 spans agrees with a brute-force map."""
+    import numpy as np
+    from kvq.engine import fp8_span_table
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        n_total = int(rng.integers(3000, 40000)) // 16 * 16
+        cuts = np.sort(rng.choice(np.arange(1, n_total // 16), size=int(rng.integers(2, 12)), replace=False)) * 16
+        bounds = [0] + cuts.tolist() + [n_total]
+        segs = [(bounds[i], bounds[i + 1] - bounds[i]) for i in range(len(bounds) - 1) if rng.random() < 0.6]      # some stretches belong to nobody
+        offs, ns = [o for o, _ in segs], [c for _, c in segs]
+        table = fp8_span_table(offs, ns, n_total)
+        owner = np.full(n_total, -1)
+        for si, (o, c) in enumerate(segs):
+            owner[o:o + c] = si
+        for k, t in enumerate(table):
+            part = owner[2048 * k: 2048 * k + 2048]
+            if t >= 0:
+                assert (part == t).all()
+            elif t == -1:
+                assert (part == -1).all()
+            else:
+                assert t == -2 and len(set(part.tolist())) > 1
+        # 8-element groups never straddle a segment (segments are multiples of 16): what the kernel's walk relies on
+        assert all((owner[e:e + 8] == owner[e]).all() for e in range(0, n_total, 8))
