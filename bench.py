@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--bucket-mib", type=int, default=64)
     ap.add_argument("--fp8", action="store_true", help="BASELINE.json configs[4]: forward GEMMs on the fp8 matrix cores where that beats the "
                     "bf16 kernel -- the LM head and the all-layer cross-K/V projection (backward bf16)")
+    ap.add_argument("--cpu-same-batch", action="store_true", help="also time the CPU restatement at THIS run's batch size (one warm-up + two "
+                    "timed steps, ~1 minute of host time): `cpu_baseline_same_batch`, the like-for-like ratio `vs_cpu_port_same_batch`")
     ap.add_argument("--no-distance-phase", action="store_true", help="skip the 9 extra steps with the three-kernel quantiser forward that time "
                     "the distance / arg-min kernel alone (roofline.distance_phase); kernel traces of the step use this")
     ap.add_argument("--fp8-wide", action="store_true", help="round 4's scope: fp8 for the LM head and the all-layer cross-K/V projection only")
@@ -413,6 +415,15 @@ def main():
                                        f"{r['threads']} cores (BASELINE.json configs[1] vs configs[0]) -- different batch size and dtype, "
                                        f"Adam over 248 M parameters dominates a batch-8 CPU step: NOT a like-for-like speed-up; "
                                        f"north_star target >= 10")
+            if a.cpu_same_batch and not a.bagon:
+                print(f"[bench] timing the CPU restatement at batch {a.batch} ...", file=sys.stderr, flush=True)
+                r2 = step_oracle.time_cpu_steps(cfg, batch=a.batch, seq_len=a.seq_len, n_e=a.codes, e_dim=D, beta=0.25,
+                                                vocab_size=model.decoder.config.vocab_size, warmup=1, steps=2, threads=cores, budget_s=1e9,
+                                                log=lambda m: print(m, file=sys.stderr, flush=True))
+                out["cpu_baseline_same_batch"] = {"value": r2["sentences_per_s"], "unit": "sentences/s", "cores": r2["threads"], "kind": "port",
+                                                  "sample": f"{r2['steps']} timed steps (median) of oracle/step_oracle.py at batch={a.batch} "
+                                                            f"seq_len={a.seq_len} f32, {r2['s_per_step']:.2f} s/step"}
+                out["vs_cpu_port_same_batch"] = out["value"] / r2["sentences_per_s"]      # same batch; dtype still bf16 against f32
         print(json.dumps(out), flush=True)
         # a line whose number means something else than it says is worse than no line: fail the run
         import math
